@@ -1,0 +1,166 @@
+/*
+ * mdhip.h -- C ABI of the MI355X-native MegaDetector v5 batch-inference hot path.
+ *
+ * The reference (agentmorris/MegaDetector) is pure Python and has NO FFI on this path; its
+ * plugin seam is the duck-typed detector object returned by
+ *   megadetector/detection/run_detector.py:601  load_detector(...)
+ * i.e. the class  megadetector/detection/pytorch_detector.py:739  PTDetector.
+ * This header is the C ABI that sits *under* that Python seam: each
+ * entry point replaces one stage of PTDetector._process_batch_group
+ * (pytorch_detector.py:1257-1426) and is bound from Python with ctypes
+ * (megadetector_amd/_lib.py; the stub a maintainer would add is shown in INTEGRATION.md).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative MDHIP_E* code, never throws, never exits.  mdhip_last_error() returns a
+ * human-readable message for the most recent failure on that context (or, with ctx == NULL,
+ * the most recent mdhip_create failure on the calling thread).  A context is bound to one GPU
+ * and is not thread-safe; use one context per (process, GPU).  The library owns all device
+ * buffers and packed weights; the caller owns every pointer it passes in.
+ */
+#ifndef MDHIP_H
+#define MDHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDHIP_OK            0
+#define MDHIP_EINVAL       -1   /* bad argument / unsupported model description */
+#define MDHIP_EHIP         -2   /* a HIP runtime call failed                     */
+#define MDHIP_ENOMEM       -3   /* device arena too small for the request        */
+#define MDHIP_EUNSUPPORTED -4   /* valid request this build does not implement   */
+
+/* arithmetic type of the conv stack */
+#define MDHIP_DTYPE_BF16 0
+#define MDHIP_DTYPE_FP8  1      /* reserved (BASELINE.json configs[4]); not implemented yet */
+
+/* module kinds of a YOLOv5 model description (yolov5 models/yolo.py:parse_model rows) */
+#define MDHIP_CONV      0
+#define MDHIP_C3        1
+#define MDHIP_SPPF      2
+#define MDHIP_UPSAMPLE  3
+#define MDHIP_CONCAT    4
+#define MDHIP_DETECT    5
+
+/* One fused (conv + folded BatchNorm) of the checkpoint: what
+ * pytorch_detector.py:957  checkpoint['model'].float().fuse()  leaves in each Conv module. */
+typedef struct {
+    const float* weight;   /* host, fp32, OIHW: [c_out][c_in][kh][kw] */
+    const float* bias;     /* host, fp32, [c_out]                      */
+    int32_t c_out, c_in, kh, kw;
+} mdhip_conv;
+
+/* One row of the model (same granularity as model.model[i] in the reference's checkpoint).
+ * from[] holds absolute layer indices (-1 = the network input).
+ * Conv:    convs[first_conv]                        k,s,p as in the module
+ * C3:      cv1, cv2, cv3, then (m[j].cv1, m[j].cv2) for j < n        -> 3 + 2n convs
+ * SPPF:    cv1, cv2 ; k = pool size
+ * Detect:  one 1x1 conv per input level (bias, no activation)        -> n_from convs */
+typedef struct {
+    int32_t type;
+    int32_t n_from;
+    int32_t from[4];
+    int32_t c_out;
+    int32_t k, s, p;
+    int32_t n;
+    int32_t shortcut;
+    int32_t first_conv;
+} mdhip_layer;
+
+typedef struct {
+    int32_t n_layers;
+    const mdhip_layer* layers;
+    int32_t n_convs;
+    const mdhip_conv* convs;
+    int32_t nc;                 /* classes (3 for MDv5)                         */
+    int32_t na;                 /* anchors per level (3)                        */
+    int32_t nl;                 /* detection levels (4 for YOLOv5x6)            */
+    const float* anchors_px;    /* host, [nl][na][2] = Detect.anchors * stride  */
+    const float* strides;       /* host, [nl]                                   */
+} mdhip_model;
+
+/* Letterbox geometry of one image, computed on the host exactly as
+ * yolov5 letterbox() does (restated at pytorch_detector.py:434-454). */
+typedef struct {
+    int32_t src_h, src_w;           /* original image                                   */
+    int32_t resized_h, resized_w;   /* new_unpad: size after cv2.resize(INTER_LINEAR)   */
+    int32_t top, left;              /* border offsets (copyMakeBorder, value 114)       */
+} mdhip_letterbox;
+
+typedef struct mdhip_ctx mdhip_ctx;
+
+/* Replaces PTDetector.__init__/_load_model (pytorch_detector.py:745-959): packs weights to
+ * the MFMA operand layout, plans and allocates every activation buffer for up to
+ * max_batch images of max_h x max_w letterboxed pixels on GPU `device`. */
+int mdhip_create(const mdhip_model* model, int device, int dtype,
+                 int max_batch, int max_h, int max_w, mdhip_ctx** out);
+void mdhip_destroy(mdhip_ctx* ctx);
+const char* mdhip_last_error(mdhip_ctx* ctx);
+
+/* Replaces letterbox() + HWC->CHW + float() + /255 (pytorch_detector.py:1104-1109,
+ * :1283-1310).  images[i]: HWC uint8 RGB, src_h x src_w, host or device memory
+ * (host memory is staged through a pinned ring).  Output: the context's network input,
+ * n x out_h x out_w.  out_h/out_w must be multiples of the model's largest stride. */
+int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_letterbox* geom,
+                     int n, int out_h, int out_w, void* hip_stream);
+
+/* Replaces self.model(batch)[0] (pytorch_detector.py:1313): conv stack + Detect decode.
+ * Leaves (n, n_anchors, 5+nc) fp32 predictions in a device buffer of the context. */
+int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream);
+
+/* Replaces nms() (pytorch_detector.py:502-610) on the predictions of the last forward.
+ * out: host, [n][max_det][6] = x1,y1,x2,y2,conf,cls in letterboxed pixels, sorted by
+ * confidence (descending; ties by anchor index); counts: host, [n].  Blocks until the
+ * results are in host memory. */
+int mdhip_nms(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_det,
+              float* out, int32_t* counts, void* hip_stream);
+
+/* nms() on caller-supplied predictions (host, [n][n_anchors][5+nc] fp32); any n_anchors up to
+ * the context's capacity.  Used by the parity tests against the reference's NMS vectors. */
+int mdhip_nms_on(mdhip_ctx* ctx, const float* pred, int n, int n_anchors, float conf_thres,
+                 float iou_thres, int max_det, float* out, int32_t* counts, void* hip_stream);
+
+/* ---- introspection / measurement (not on the product path) ---- */
+
+int mdhip_num_anchors(mdhip_ctx* ctx, int h, int w);                 /* anchors per image  */
+int mdhip_max_stride(mdhip_ctx* ctx);
+/* copy the raw predictions of the last forward to host: [n][n_anchors][5+nc] fp32 */
+int mdhip_read_predictions(mdhip_ctx* ctx, int n, float* out, void* hip_stream);
+/* copy the network input of the last preprocess to host as [n][3][h][w] fp32 (in [0,1]) */
+int mdhip_read_input(mdhip_ctx* ctx, int n, int h, int w, float* out, void* hip_stream);
+/* copy the output of model layer `layer` (last forward) to host as NCHW fp32; returns
+ * c,h,w through the out-params; out may be NULL to query the shape only */
+int mdhip_read_layer(mdhip_ctx* ctx, int layer, int n, float* out, int* c, int* h, int* w,
+                     void* hip_stream);
+
+typedef struct {
+    char    name[48];       /* e.g. "L6.m3.cv2 3x3"                           */
+    int32_t kind;           /* 0 conv (implicit GEMM), 1 pool, 2 upsample, 3 decode, 4 copy */
+    int32_t layer;          /* model layer index                              */
+    int32_t m, n, k;        /* GEMM view of a conv (per call, for the last n,h,w) */
+    double  flops;          /* algorithmic FLOPs of the op for the last (n,h,w)   */
+    double  bytes;          /* algorithmic HBM bytes (read input once + write output once + weights) */
+    int32_t cfg;            /* tile configuration chosen                      */
+} mdhip_op_info;
+
+int mdhip_num_ops(mdhip_ctx* ctx);
+int mdhip_get_op_info(mdhip_ctx* ctx, int op, mdhip_op_info* out);
+/* run the forward with a hipEvent pair around every op; ms[op] = duration in milliseconds */
+int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hip_stream);
+/* force tile configuration `cfg` for op `op` (-1 = automatic choice); returns MDHIP_EINVAL
+ * when cfg does not fit the op.  mdhip_num_conv_cfgs() = number of configurations. */
+int mdhip_set_op_cfg(mdhip_ctx* ctx, int op, int cfg);
+int mdhip_num_conv_cfgs(void);
+/* time one op in isolation: `iters` back-to-back launches bracketed by events */
+int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float* ms_avg,
+                  void* hip_stream);
+
+const char* mdhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDHIP_H */

@@ -1,0 +1,293 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): bf16 operands, fp32 MFMA accumulation,
+// bias + SiLU (+ residual) fused into the epilogue, output written straight into a channel
+// slice of the consumer's buffer (concat-by-construction).
+//
+// Replaces the cuDNN/MIOpen conv2d + SiLU (+ add, + cat) kernels PyTorch launches under
+//   reference megadetector/detection/pytorch_detector.py:1313   self.model(batch_tensor)
+// for every Conv module of the YOLOv5x6 graph (SURVEY.md section 8(a) P4 layer table).
+//
+// GEMM view:  C[M][N] = A[M][K] * W[N][K]^T
+//   M = batch*Ho*Wo output pixels (NHWC, pixel-major), N = C_out, K = kh*kw*C_in ordered
+//   (r, s, c) so that every 16-byte chunk (8 channels) of an A row is contiguous in HBM.
+//
+// Data movement (per workgroup, per 64-wide K slab):
+//   HBM/L2 --global_load_lds 16B/lane--> LDS  (no VGPR round trip; the per-lane *source*
+//   address does the im2col gather, zero padding reads a 16-byte zero page)
+//   LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row & 7) on the source
+//   side and on the ds_read_b128 side (guide rule 21: linear LDS destination, same involution
+//   on source and read) so that fragment reads are bank-conflict free.
+//   Two LDS stages: the loads of slab k+1 are in flight while slab k feeds the MFMAs.
+//
+// MFMA: v_mfma_f32_16x16x32_bf16 with the operands swapped (weights as "A", pixels as "B") so
+//   that each lane ends up with 4 *consecutive output channels* of one pixel: the epilogue is
+//   lane-local (bias, SiLU, residual, bf16 pack) and stores 8 contiguous bytes per fragment.
+//
+// Workgroup -> tile mapping is XCD-aware: consecutive tiles (which share im2col halo rows
+//   and the weight panel) are placed on the same XCD/L2.
+
+#include "mdhip_internal.h"
+
+namespace mdhip {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MDHIP_GLDS16(gptr, lptr)                                                        \
+    __builtin_amdgcn_global_load_lds(                                                   \
+        (const __attribute__((address_space(1))) void*)(gptr),                          \
+        (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+__device__ __forceinline__ float silu_f32(float x) {
+    return x / (1.0f + __expf(-x));
+}
+
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64)
+conv_igemm_kernel(const ConvArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 8;                 // 8 rows x 128 B per wave-instruction
+    constexpr int B_INSTR = BN / 8;
+    constexpr int A_PER = A_INSTR / NW;
+    constexpr int B_PER = (B_INSTR + NW - 1) / NW;
+    static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- XCD-aware tile mapping (bijective; block b runs on XCD b % 8) -----------------
+    int tile_m, tile_n;
+    {
+        const int bid = blockIdx.x, nwg = gridDim.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile_n = lin % p.tiles_n;
+        tile_m = lin / p.tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- loader geometry ---------------------------------------------------------------
+    const int lr = lane >> 3;              // row inside an 8-row load instruction (== row & 7)
+    const int jj = (lane & 7) ^ lr;        // swizzled source chunk inside the 128-byte K slab
+
+    const uint16_t* a_ptr[A_PER];
+    uint32_t a_mask[A_PER];
+    const int kh = p.ntaps / p.kw;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int row = (i * NW + wave) * 8 + lr;
+        const int m = m0 + row;
+        uint32_t mask = 0;
+        const uint16_t* ptr = p.in;
+        if (m < p.M) {
+            const int b = m / p.HoWo;
+            const int rem = m - b * p.HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad;
+            const int ix0 = ox * p.stride - p.pad;
+            ptr = p.in + ((long long)(b * p.H + iy0) * p.W + ix0) * p.ld_in;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)          // kernels are 1x1 or 3x3 (planner enforces it)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (r < kh && s < p.kw && (unsigned)(iy0 + r) < (unsigned)p.H &&
+                        (unsigned)(ix0 + s) < (unsigned)p.W)
+                        mask |= 1u << (r * p.kw + s);
+        }
+        a_ptr[i] = ptr;
+        a_mask[i] = mask;
+    }
+    const uint16_t* b_ptr[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int n = n0 + (i * NW + wave) * 8 + lr;
+        b_ptr[i] = (n < p.n_rows) ? p.wgt + (size_t)n * p.k_pad + jj * 8 : nullptr;
+    }
+
+    // per-lane position inside K: chunk c8 of tap (tr, ts)
+    int c8 = jj, tap = 0, tr = 0, ts = 0;
+    while (c8 >= p.C8) {
+        c8 -= p.C8;
+        ++tap;
+        if (++ts == p.kw) { ts = 0; ++tr; }
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + A_BYTES;
+        const bool tap_ok = tap < p.ntaps;
+        const int tapoff = (tr * p.W + ts) * p.ld_in + c8 * 8;
+        const uint32_t bit = tap_ok ? (1u << (tap & 31)) : 0u;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const uint16_t* src = (a_mask[i] & bit) ? a_ptr[i] + tapoff : p.zero;
+            MDHIP_GLDS16(src, sA + (i * NW + wave) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int instr = i * NW + wave;
+            if (instr < B_INSTR) {
+                const uint16_t* src = b_ptr[i] ? b_ptr[i] + kt * 64 : p.zero;
+                MDHIP_GLDS16(src, sB + instr * 1024);
+            }
+        }
+        // advance this lane's K position by one slab (8 chunks)
+        c8 += 8;
+        while (c8 >= p.C8) {
+            c8 -= p.C8;
+            ++tap;
+            if (++ts == p.kw) { ts = 0; ++tr; }
+        }
+    };
+
+    // ---- fragment read offsets ---------------------------------------------------------
+    // lane reads row (lane & 15) of a 16-row fragment, 16-byte chunk (kk*4 + (lane >> 4)),
+    // stored at chunk ^ (row & 7)
+    const int frag_row_off = (lane & 15) * 128;
+    const int frag_ch0 = (((lane >> 4) ^ (lane & 7)) * 16);      // kk = 0 ; kk = 1 is ^ 64
+    const int a_frag_base = (wm * TM) * 128 + frag_row_off;
+    const int b_frag_base = A_BYTES + (wn * TN) * 128 + frag_row_off;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = p.k_pad >> 6;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+
+        const char* sbase = smem + cur * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int choff = frag_ch0 ^ (kk * 64);
+            bf16x8 xf[FM], wf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                xf[i] = *(const bf16x8*)(sbase + a_frag_base + i * 2048 + choff);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                wf[j] = *(const bf16x8*)(sbase + b_frag_base + j * 2048 + choff);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels n..n+3 of pixel m --------------------------------
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * TM + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            const float4 bv = *(const float4*)(p.bias + n);
+            float v0 = acc[i][j][0] + bv.x;
+            float v1 = acc[i][j][1] + bv.y;
+            float v2 = acc[i][j][2] + bv.z;
+            float v3 = acc[i][j][3] + bv.w;
+            if (p.act) {
+                v0 = silu_f32(v0); v1 = silu_f32(v1); v2 = silu_f32(v2); v3 = silu_f32(v3);
+            }
+            if (p.res) {
+                const uint2 rv = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
+                v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff));
+                v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
+                v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff));
+                v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+            }
+            if (p.out_f32) {
+                *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v0, v1, v2, v3);
+            } else {
+                uint2 o;
+                o.x = pack2_bf16(v0, v1);
+                o.y = pack2_bf16(v2, v3);
+                *(uint2*)((uint16_t*)p.out + (size_t)m * p.ld_out + n) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// configuration table
+// ---------------------------------------------------------------------------------------
+#define MDHIP_CONV_CFGS(X) \
+    X(0, 256, 160, 4, 2)   \
+    X(1, 128, 160, 2, 2)   \
+    X(2, 256, 80, 4, 1)    \
+    X(3, 128, 80, 4, 1)    \
+    X(4, 256, 32, 4, 1)    \
+    X(5, 128, 64, 2, 2)    \
+    X(6, 128, 128, 2, 2)   \
+    X(7, 256, 128, 4, 2)   \
+    X(8, 128, 320, 2, 4)   \
+    X(9, 64, 160, 1, 2)    \
+    X(10, 64, 64, 1, 2)    \
+    X(11, 256, 64, 4, 1)
+
+static const ConvCfg g_cfgs[] = {
+#define X(id, bm, bn, wm, wn) {bm, bn, (wm) * (wn) * 64, (size_t)2 * ((bm) + (bn)) * 128, #bm "x" #bn "/" #wm "x" #wn},
+    MDHIP_CONV_CFGS(X)
+#undef X
+};
+
+int conv_num_cfgs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
+const ConvCfg& conv_cfg(int i) { return g_cfgs[i]; }
+
+hipError_t conv_init() {
+    hipError_t e = hipSuccess;
+#define X(id, bm, bn, wm, wn)                                                                      \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<bm, bn, wm, wn>,                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs[id].lds_bytes);
+    MDHIP_CONV_CFGS(X)
+#undef X
+    return e;
+}
+
+hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
+    if (cfg < 0 || cfg >= conv_num_cfgs()) return hipErrorInvalidValue;
+    const ConvCfg& c = g_cfgs[cfg];
+    ConvArgs p = a;
+    p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;
+    const int tiles_m = (a.M + c.bm - 1) / c.bm;
+    const dim3 grid((unsigned)(tiles_m * p.tiles_n));
+    switch (cfg) {
+#define X(id, bm, bn, wm, wn)                                                                     \
+    case id:                                                                                      \
+        hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn>), grid, dim3((wm) * (wn) * 64),     \
+                           c.lds_bytes, s, p);                                                    \
+        break;
+        MDHIP_CONV_CFGS(X)
+#undef X
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mdhip

@@ -1,0 +1,970 @@
+// C-ABI layer (include/mdhip.h): model planning, weight packing, buffer arena, executor.
+//
+// This is the native runtime under the Python detector seam
+// (reference megadetector/detection/pytorch_detector.py:739 PTDetector):
+//   mdhip_create      <- PTDetector.__init__/_load_model            (:745-959)
+//   mdhip_preprocess  <- letterbox + tensor prep                    (:1104-1109, :1283-1310)
+//   mdhip_forward     <- self.model(batch)[0]                       (:1313)
+//   mdhip_nms         <- nms()                                      (:502-610, :1342)
+//
+// Planning turns the YOLOv5 module list into a flat list of ops over channel-strided NHWC
+// bf16 views of one device arena:
+//   * Concat never copies: producers write straight into their channel slice of the consumer's
+//     buffer (a copy op is emitted only for a producer that already lives elsewhere).
+//   * C3:  cv1 and cv2 read the same input -> ONE implicit GEMM with the two weight sets
+//     stacked along N writes the [m-branch | cv2] concat buffer; the bottleneck chain then
+//     updates the first half in place (1x1 -> scratch, 3x3 (+residual) -> slice).
+//   * the 6x6/s2 stem runs as a 3x3/s1 conv over the space-to-depth input the letterbox
+//     kernel produces.
+//   * Detect: per level a 1x1 implicit GEMM with fp32 output followed by the decode kernel.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mdhip.h"
+#include "mdhip_internal.h"
+
+using namespace mdhip;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Tensor {
+    size_t off = 0;   // byte offset into the arena
+    int ld = 0;       // elements between consecutive pixels
+    int c = 0;        // channels of the view
+    int div = 1;      // spatial size = network input / div
+    bool valid = false;
+};
+
+struct PackedConv {
+    size_t w_off = 0, b_off = 0;     // byte offsets into the weight arena
+    int n_rows = 0, k_pad = 0, cin_pad = 0, kh = 0, kw = 0, c_out = 0, k_real = 0;
+};
+
+enum OpKind { OP_CONV = 0, OP_POOL = 1, OP_UPSAMPLE = 2, OP_DECODE = 3, OP_COPY = 4 };
+
+struct Op {
+    int kind = OP_CONV;
+    int layer = -1;
+    std::string name;
+    Tensor in, out, res;
+    bool has_res = false;
+    int pc = -1;
+    int stride = 1, pad = 0, act = 1, out_f32 = 0;
+    int pool_k = 5;
+    int level = 0;            // decode
+    size_t f32_off = 0;       // decode: logits buffer offset ; conv with out_f32: same
+    int f32_ld = 0;
+    int forced_cfg = -1;
+    int last_cfg = -1;
+    // stats for the last (n,h,w)
+    int gm = 0, gn = 0, gk = 0;
+    double flops = 0, bytes = 0;
+};
+
+}  // namespace
+
+struct mdhip_ctx {
+    int device = 0;
+    int dtype = 0;
+    int max_batch = 0, max_h = 0, max_w = 0;
+    int nc = 0, na = 0, nl = 0, no = 0;
+    std::vector<float> strides;
+    int max_stride = 0;
+    std::vector<mdhip_layer> layers;
+    std::vector<Tensor> layer_out;
+    std::vector<PackedConv> packed;
+    std::vector<Op> ops;
+    Tensor input;                 // space-to-depth network input (16 channels, div 2)
+    size_t arena_bytes = 0;
+    char* arena = nullptr;
+    char* warena = nullptr;       // packed weights + biases + zero page + anchors
+    size_t warena_bytes = 0;
+    size_t zero_off = 0, anchors_off = 0;
+    size_t pred_off = 0;          // fp32 predictions [max_batch][A_max][no]
+    int a_max = 0;
+    NmsScratch nms_scr{};
+    size_t nms_out_off = 0, nms_cnt_off = 0;
+    size_t geom_off = 0;
+    char* stage = nullptr;        // device staging for host images
+    size_t stage_bytes = 0;
+    int last_n = 0, last_h = 0, last_w = 0;
+    std::string err;
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+int fail(mdhip_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(ctx, MDHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------
+// planner
+// ---------------------------------------------------------------------------------------
+struct Planner {
+    mdhip_ctx* ctx;
+    const mdhip_model* model;
+    size_t cursor = 0;
+    std::vector<std::vector<uint16_t>> w_host;   // packed weights per PackedConv
+    std::vector<std::vector<float>> b_host;
+    std::vector<int> layer_c, layer_div;
+    std::vector<int> concat_target, concat_choff;   // per producer layer
+    std::vector<Tensor> concat_buf;                  // per concat layer
+    std::string error;
+
+    Tensor alloc(int c, int div) {
+        Tensor t;
+        t.off = cursor;
+        t.ld = c;
+        t.c = c;
+        t.div = div;
+        t.valid = true;
+        const size_t px = (size_t)ctx->max_batch * (ctx->max_h / div) * (ctx->max_w / div);
+        cursor = align_up(cursor + px * c * 2, 256);
+        return t;
+    }
+    size_t alloc_bytes(size_t bytes) {
+        const size_t off = cursor;
+        cursor = align_up(cursor + bytes, 256);
+        return off;
+    }
+    static Tensor slice(const Tensor& t, int ch_off, int c) {
+        Tensor s = t;
+        s.off = t.off + (size_t)ch_off * 2;
+        s.c = c;
+        return s;
+    }
+
+    // pack one or more OIHW fp32 convs (stacked along N) to bf16 [n_rows][k_pad], k = (r,s,c)
+    int pack(const std::vector<const mdhip_conv*>& cs, bool s2d_stem) {
+        PackedConv pc;
+        const mdhip_conv* c0 = cs[0];
+        int c_out = 0;
+        for (auto* c : cs) c_out += c->c_out;
+        if (s2d_stem) {
+            pc.kh = pc.kw = 3;
+            pc.cin_pad = 16;
+            pc.k_real = 6 * 6 * 3;
+        } else {
+            pc.kh = c0->kh;
+            pc.kw = c0->kw;
+            pc.cin_pad = round_up(c0->c_in, 8);
+            pc.k_real = c0->kh * c0->kw * c0->c_in;
+        }
+        pc.c_out = c_out;
+        pc.n_rows = round_up(c_out, 16);
+        pc.k_pad = round_up(pc.kh * pc.kw * pc.cin_pad, 64);
+        std::vector<uint16_t> w((size_t)pc.n_rows * pc.k_pad, 0);
+        std::vector<float> b(pc.n_rows, 0.f);
+        int row0 = 0;
+        for (auto* c : cs) {
+            for (int o = 0; o < c->c_out; ++o) {
+                uint16_t* dst = &w[(size_t)(row0 + o) * pc.k_pad];
+                b[row0 + o] = c->bias ? c->bias[o] : 0.f;
+                if (s2d_stem) {
+                    // w6[o][c][6][6] -> w3[o][r'][s'][(dy*2+dx)*3 + c], 6x6 index = 2*r'+dy
+                    for (int ci = 0; ci < 3; ++ci)
+                        for (int r = 0; r < 6; ++r)
+                            for (int s = 0; s < 6; ++s) {
+                                const float v = c->weight[(((size_t)o * 3 + ci) * 6 + r) * 6 + s];
+                                const int rp = r >> 1, dy = r & 1, sp = s >> 1, dx = s & 1;
+                                dst[(rp * 3 + sp) * 16 + (dy * 2 + dx) * 3 + ci] = f32_to_bf16(v);
+                            }
+                } else {
+                    for (int ci = 0; ci < c->c_in; ++ci)
+                        for (int r = 0; r < c->kh; ++r)
+                            for (int s = 0; s < c->kw; ++s) {
+                                const float v =
+                                    c->weight[(((size_t)o * c->c_in + ci) * c->kh + r) * c->kw + s];
+                                dst[(r * c->kw + s) * pc.cin_pad + ci] = f32_to_bf16(v);
+                            }
+                }
+            }
+            row0 += c->c_out;
+        }
+        ctx->packed.push_back(pc);
+        w_host.push_back(std::move(w));
+        b_host.push_back(std::move(b));
+        return (int)ctx->packed.size() - 1;
+    }
+
+    void add_conv(int layer, const std::string& name, const Tensor& in, const Tensor& out, int pc,
+                  int stride, int pad, bool act, const Tensor* res) {
+        Op op;
+        op.kind = OP_CONV;
+        op.layer = layer;
+        op.name = name;
+        op.in = in;
+        op.out = out;
+        op.pc = pc;
+        op.stride = stride;
+        op.pad = pad;
+        op.act = act ? 1 : 0;
+        if (res) { op.res = *res; op.has_res = true; }
+        ctx->ops.push_back(op);
+    }
+
+    bool plan() {
+        const int nL = model->n_layers;
+        layer_c.assign(nL, 0);
+        layer_div.assign(nL, 1);
+        concat_target.assign(nL, -1);
+        concat_choff.assign(nL, 0);
+        concat_buf.assign(nL, Tensor());
+        ctx->layer_out.assign(nL, Tensor());
+        char nm[96];
+
+        // pass 1: channels / divisors / concat targets
+        for (int i = 0; i < nL; ++i) {
+            const mdhip_layer& L = model->layers[i];
+            for (int j = 0; j < L.n_from; ++j)
+                if (L.from[j] >= i || L.from[j] < -1) { error = "layer 'from' index out of order"; return false; }
+            const int f0 = L.n_from > 0 ? L.from[0] : -1;
+            const int in_div = f0 < 0 ? 1 : layer_div[f0];
+            switch (L.type) {
+                case MDHIP_CONV:
+                    layer_c[i] = L.c_out;
+                    layer_div[i] = in_div * L.s;
+                    break;
+                case MDHIP_C3:
+                case MDHIP_SPPF:
+                    layer_c[i] = L.c_out;
+                    layer_div[i] = in_div;
+                    break;
+                case MDHIP_UPSAMPLE:
+                    if (f0 < 0 || in_div % 2) { error = "bad upsample input"; return false; }
+                    layer_c[i] = layer_c[f0];
+                    layer_div[i] = in_div / 2;
+                    break;
+                case MDHIP_CONCAT: {
+                    int c = 0;
+                    for (int j = 0; j < L.n_from; ++j) {
+                        const int f = L.from[j];
+                        if (f < 0 || layer_div[f] != in_div) { error = "concat inputs differ in size"; return false; }
+                        if (concat_target[f] < 0) { concat_target[f] = i; concat_choff[f] = c; }
+                        c += layer_c[f];
+                    }
+                    layer_c[i] = c;
+                    layer_div[i] = in_div;
+                    break;
+                }
+                case MDHIP_DETECT:
+                    break;
+                default:
+                    error = "unknown layer type";
+                    return false;
+            }
+            if (L.type != MDHIP_DETECT && L.type != MDHIP_CONCAT && (layer_c[i] % 8)) {
+                error = "channel counts must be multiples of 8";
+                return false;
+            }
+        }
+
+        // network input (space-to-depth, 16 channels)
+        ctx->input = alloc(16, 2);
+
+        auto out_view = [&](int i) -> Tensor {
+            const int tgt = concat_target[i];
+            if (tgt >= 0) {
+                if (!concat_buf[tgt].valid) concat_buf[tgt] = alloc(layer_c[tgt], layer_div[tgt]);
+                return slice(concat_buf[tgt], concat_choff[i], layer_c[i]);
+            }
+            return alloc(layer_c[i], layer_div[i]);
+        };
+
+        // pass 2: ops
+        for (int i = 0; i < nL; ++i) {
+            const mdhip_layer& L = model->layers[i];
+            const int f0 = L.n_from > 0 ? L.from[0] : -1;
+            if (f0 < 0 && !(L.type == MDHIP_CONV && i == 0)) { error = "only the stem conv (layer 0) may read the network input"; return false; }
+            if (L.type != MDHIP_DETECT && L.type != MDHIP_CONCAT && L.type != MDHIP_UPSAMPLE &&
+                (L.first_conv < 0 || L.first_conv >= model->n_convs)) { error = "first_conv out of range"; return false; }
+            switch (L.type) {
+                case MDHIP_CONV: {
+                    const mdhip_conv* c = &model->convs[L.first_conv];
+                    Tensor out = out_view(i);
+                    if (f0 < 0) {
+                        if (!(c->c_in == 3 && c->kh == 6 && c->kw == 6 && L.s == 2 && L.p == 2)) {
+                            error = "stem must be Conv(3->c, k=6, s=2, p=2)";
+                            return false;
+                        }
+                        const int pc = pack({c}, true);
+                        snprintf(nm, sizeof(nm), "L%d stem 6x6s2 (3x3 s2d)", i);
+                        add_conv(i, nm, ctx->input, out, pc, 1, 1, true, nullptr);
+                    } else {
+                        if (c->c_in != layer_c[f0] || c->kh != L.k || c->kw != L.k) { error = "conv shape mismatch"; return false; }
+                        if (L.k != 1 && L.k != 3) { error = "only 1x1 and 3x3 convs supported"; return false; }
+                        const int pc = pack({c}, false);
+                        snprintf(nm, sizeof(nm), "L%d conv %dx%ds%d", i, L.k, L.k, L.s);
+                        add_conv(i, nm, ctx->layer_out[f0], out, pc, L.s, L.p, true, nullptr);
+                    }
+                    ctx->layer_out[i] = out;
+                    break;
+                }
+                case MDHIP_C3: {
+                    const mdhip_conv* cv = &model->convs[L.first_conv];
+                    const int ch = cv[0].c_out;          // hidden width c_
+                    if (ch % 8 || cv[1].c_out != ch || cv[0].c_in != layer_c[f0]) { error = "C3 shape mismatch"; return false; }
+                    Tensor out = out_view(i);
+                    Tensor Y = alloc(2 * ch, layer_div[i]);
+                    Tensor T = alloc(ch, layer_div[i]);
+                    Tensor Y1 = slice(Y, 0, ch);
+                    int pc = pack({&cv[0], &cv[1]}, false);
+                    snprintf(nm, sizeof(nm), "L%d C3.cv1|cv2 1x1", i);
+                    add_conv(i, nm, ctx->layer_out[f0], Y, pc, 1, 0, true, nullptr);
+                    for (int j = 0; j < L.n; ++j) {
+                        const mdhip_conv* b1 = &cv[3 + 2 * j];
+                        const mdhip_conv* b2 = &cv[4 + 2 * j];
+                        if (b1->kh != 1 || b2->kh != 3) { error = "bottleneck must be 1x1 then 3x3"; return false; }
+                        pc = pack({b1}, false);
+                        snprintf(nm, sizeof(nm), "L%d C3.m%d.cv1 1x1", i, j);
+                        add_conv(i, nm, Y1, T, pc, 1, 0, true, nullptr);
+                        pc = pack({b2}, false);
+                        snprintf(nm, sizeof(nm), "L%d C3.m%d.cv2 3x3", i, j);
+                        add_conv(i, nm, T, Y1, pc, 1, 1, true, L.shortcut ? &Y1 : nullptr);
+                    }
+                    pc = pack({&cv[2]}, false);
+                    snprintf(nm, sizeof(nm), "L%d C3.cv3 1x1", i);
+                    add_conv(i, nm, Y, out, pc, 1, 0, true, nullptr);
+                    ctx->layer_out[i] = out;
+                    break;
+                }
+                case MDHIP_SPPF: {
+                    const mdhip_conv* cv = &model->convs[L.first_conv];
+                    const int ch = cv[0].c_out;
+                    if (ch % 8) { error = "SPPF hidden width must be a multiple of 8"; return false; }
+                    Tensor out = out_view(i);
+                    Tensor Y = alloc(4 * ch, layer_div[i]);
+                    int pc = pack({&cv[0]}, false);
+                    snprintf(nm, sizeof(nm), "L%d SPPF.cv1 1x1", i);
+                    add_conv(i, nm, ctx->layer_out[f0], slice(Y, 0, ch), pc, 1, 0, true, nullptr);
+                    Op pool;
+                    pool.kind = OP_POOL;
+                    pool.layer = i;
+                    snprintf(nm, sizeof(nm), "L%d SPPF.pool x3 k%d", i, L.k);
+                    pool.name = nm;
+                    pool.in = slice(Y, 0, ch);
+                    pool.out = Y;
+                    pool.pool_k = L.k;
+                    ctx->ops.push_back(pool);
+                    pc = pack({&cv[1]}, false);
+                    snprintf(nm, sizeof(nm), "L%d SPPF.cv2 1x1", i);
+                    add_conv(i, nm, Y, out, pc, 1, 0, true, nullptr);
+                    ctx->layer_out[i] = out;
+                    break;
+                }
+                case MDHIP_UPSAMPLE: {
+                    Tensor out = out_view(i);
+                    Op op;
+                    op.kind = OP_UPSAMPLE;
+                    op.layer = i;
+                    snprintf(nm, sizeof(nm), "L%d upsample x2", i);
+                    op.name = nm;
+                    op.in = ctx->layer_out[f0];
+                    op.out = out;
+                    ctx->ops.push_back(op);
+                    ctx->layer_out[i] = out;
+                    break;
+                }
+                case MDHIP_CONCAT: {
+                    if (!concat_buf[i].valid) concat_buf[i] = alloc(layer_c[i], layer_div[i]);
+                    // a concat feeding another concat keeps its own buffer and is copied below
+                    int c = 0;
+                    for (int j = 0; j < L.n_from; ++j) {
+                        const int f = L.from[j];
+                        if (!(concat_target[f] == i && concat_choff[f] == c)) {
+                            Op op;
+                            op.kind = OP_COPY;
+                            op.layer = i;
+                            snprintf(nm, sizeof(nm), "L%d concat copy of L%d", i, f);
+                            op.name = nm;
+                            op.in = ctx->layer_out[f];
+                            op.out = slice(concat_buf[i], c, layer_c[f]);
+                            ctx->ops.push_back(op);
+                        }
+                        c += layer_c[f];
+                    }
+                    ctx->layer_out[i] = concat_buf[i];
+                    if (concat_target[i] >= 0) {
+                        // nested concat: copy into the outer buffer
+                        Tensor outer = out_view(i);
+                        Op op;
+                        op.kind = OP_COPY;
+                        op.layer = i;
+                        snprintf(nm, sizeof(nm), "L%d nested concat copy", i);
+                        op.name = nm;
+                        op.in = concat_buf[i];
+                        op.out = outer;
+                        ctx->ops.push_back(op);
+                    }
+                    break;
+                }
+                case MDHIP_DETECT: {
+                    if (L.n_from != model->nl) { error = "Detect inputs != nl"; return false; }
+                    for (int l = 0; l < L.n_from; ++l) {
+                        const mdhip_conv* c = &model->convs[L.first_conv + l];
+                        const int f = L.from[l];
+                        if (c->c_out != ctx->na * ctx->no || c->c_in != layer_c[f] || c->kh != 1) { error = "Detect conv shape mismatch"; return false; }
+                        if (std::fabs(ctx->strides[l] - (float)layer_div[f]) > 1e-6f) { error = "Detect stride does not match the graph"; return false; }
+                        const int pc = pack({c}, false);
+                        Op op;
+                        op.kind = OP_CONV;
+                        op.layer = i;
+                        snprintf(nm, sizeof(nm), "L%d Detect.m%d 1x1", i, l);
+                        op.name = nm;
+                        op.in = ctx->layer_out[f];
+                        op.pc = pc;
+                        op.stride = 1;
+                        op.pad = 0;
+                        op.act = 0;
+                        op.out_f32 = 1;
+                        op.f32_ld = ctx->packed[pc].n_rows;
+                        const size_t px = (size_t)ctx->max_batch * (ctx->max_h / layer_div[f]) * (ctx->max_w / layer_div[f]);
+                        op.f32_off = alloc_bytes(px * op.f32_ld * 4);
+                        op.out = op.in;   // spatial size only
+                        op.out.c = c->c_out;
+                        ctx->ops.push_back(op);
+                        Op dec;
+                        dec.kind = OP_DECODE;
+                        dec.layer = i;
+                        snprintf(nm, sizeof(nm), "L%d Detect.decode%d", i, l);
+                        dec.name = nm;
+                        dec.in = op.in;
+                        dec.level = l;
+                        dec.f32_off = op.f32_off;
+                        dec.f32_ld = op.f32_ld;
+                        ctx->ops.push_back(dec);
+                    }
+                    break;
+                }
+            }
+        }
+        return true;
+    }
+};
+
+int num_anchors_for(const mdhip_ctx* ctx, int h, int w) {
+    int a = 0;
+    for (int l = 0; l < ctx->nl; ++l) {
+        const int s = (int)ctx->strides[l];
+        a += ctx->na * (h / s) * (w / s);
+    }
+    return a;
+}
+
+int check_shape(mdhip_ctx* ctx, int n, int h, int w) {
+    if (n < 1 || n > ctx->max_batch) return fail(ctx, MDHIP_EINVAL, "batch %d outside [1,%d]", n, ctx->max_batch);
+    if (h < ctx->max_stride || w < ctx->max_stride || h % ctx->max_stride || w % ctx->max_stride)
+        return fail(ctx, MDHIP_EINVAL, "input %dx%d must be a positive multiple of the model stride %d", h, w, ctx->max_stride);
+    if ((size_t)h * w > (size_t)ctx->max_h * ctx->max_w)
+        return fail(ctx, MDHIP_ENOMEM, "input %dx%d exceeds the planned %dx%d", h, w, ctx->max_h, ctx->max_w);
+    return MDHIP_OK;
+}
+
+// heuristic tile choice; measured overrides arrive through mdhip_set_op_cfg
+int choose_cfg(int M, int n_rows) {
+    static const float quality[] = {1.00f, 0.90f, 0.85f, 0.70f, 0.45f, 0.60f, 0.85f, 0.95f, 1.00f, 0.60f, 0.40f, 0.65f};
+    int best = 0;
+    float best_score = -1.f;
+    for (int i = 0; i < conv_num_cfgs(); ++i) {
+        const ConvCfg& c = conv_cfg(i);
+        const int tn = (n_rows + c.bn - 1) / c.bn, tm = (M + c.bm - 1) / c.bm;
+        const float useful = ((float)n_rows / (tn * c.bn)) * ((float)M / ((float)tm * c.bm));
+        const float fill = std::min(1.0f, (float)tm * tn / 512.0f);
+        const float score = useful * (0.35f + 0.65f * fill) * quality[i];
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    return best;
+}
+
+void fill_conv_args(mdhip_ctx* ctx, Op& op, int n, int h, int w, ConvArgs& a) {
+    const PackedConv& pc = ctx->packed[op.pc];
+    const int H = h / op.in.div, W = w / op.in.div;
+    const int Ho = H / op.stride, Wo = W / op.stride;
+    a.in = (const uint16_t*)(ctx->arena + op.in.off);
+    a.wgt = (const uint16_t*)(ctx->warena + pc.w_off);
+    a.bias = (const float*)(ctx->warena + pc.b_off);
+    a.zero = (const uint16_t*)(ctx->warena + ctx->zero_off);
+    a.ld_in = op.in.ld;
+    a.H = H;
+    a.W = W;
+    a.C8 = pc.cin_pad / 8;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.HoWo = Ho * Wo;
+    a.M = n * Ho * Wo;
+    a.N = pc.c_out;
+    a.n_rows = pc.n_rows;
+    a.k_pad = pc.k_pad;
+    a.ntaps = pc.kh * pc.kw;
+    a.kw = pc.kw;
+    a.stride = op.stride;
+    a.pad = op.pad;
+    a.act = op.act;
+    a.out_f32 = op.out_f32;
+    if (op.out_f32) {
+        a.out = ctx->arena + op.f32_off;
+        a.ld_out = op.f32_ld;
+    } else {
+        a.out = ctx->arena + op.out.off;
+        a.ld_out = op.out.ld;
+    }
+    a.res = op.has_res ? (const uint16_t*)(ctx->arena + op.res.off) : nullptr;
+    a.ld_res = op.has_res ? op.res.ld : 0;
+    a.tiles_n = 1;
+    op.gm = a.M;
+    op.gn = pc.c_out;
+    op.gk = pc.k_real;
+    op.flops = 2.0 * (double)a.M * pc.c_out * pc.k_real;
+    const double in_px = (double)n * H * W;
+    op.bytes = in_px * op.in.c * 2.0 + (double)a.M * pc.c_out * (op.out_f32 ? 4.0 : 2.0) +
+               (double)pc.c_out * pc.k_real * 2.0 + (op.has_res ? (double)a.M * pc.c_out * 2.0 : 0.0);
+}
+
+int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
+    switch (op.kind) {
+        case OP_CONV: {
+            ConvArgs a;
+            fill_conv_args(ctx, op, n, h, w, a);
+            const int cfg = op.forced_cfg >= 0 ? op.forced_cfg : choose_cfg(a.M, a.n_rows);
+            op.last_cfg = cfg;
+            HIP_TRY(ctx, conv_launch(cfg, a, s));
+            break;
+        }
+        case OP_POOL: {
+            const int H = h / op.in.div, W = w / op.in.div;
+            op.flops = 0;
+            op.bytes = (double)n * H * W * op.in.c * 2.0 * 4.0;
+            HIP_TRY(ctx, launch_sppf_pool((uint16_t*)(ctx->arena + op.out.off), op.out.ld, op.in.c, n, H, W, op.pool_k, s));
+            break;
+        }
+        case OP_UPSAMPLE: {
+            const int H = h / op.in.div, W = w / op.in.div;
+            op.bytes = (double)n * H * W * op.in.c * 2.0 * 5.0;
+            HIP_TRY(ctx, launch_upsample2x((const uint16_t*)(ctx->arena + op.in.off), op.in.ld,
+                                           (uint16_t*)(ctx->arena + op.out.off), op.out.ld, op.in.c, n, H, W, s));
+            break;
+        }
+        case OP_COPY: {
+            const long long px = (long long)n * (h / op.in.div) * (w / op.in.div);
+            op.bytes = (double)px * op.in.c * 4.0;
+            HIP_TRY(ctx, launch_copy_view((const uint16_t*)(ctx->arena + op.in.off), op.in.ld,
+                                          (uint16_t*)(ctx->arena + op.out.off), op.out.ld, op.in.c, px, s));
+            break;
+        }
+        case OP_DECODE: {
+            const int ny = h / op.in.div, nx = w / op.in.div;
+            int level_off = 0;
+            for (int l = 0; l < op.level; ++l) {
+                const int sl = (int)ctx->strides[l];
+                level_off += ctx->na * (h / sl) * (w / sl);
+            }
+            const int A = num_anchors_for(ctx, h, w);
+            op.bytes = (double)n * ny * nx * ctx->na * ctx->no * 8.0;
+            HIP_TRY(ctx, launch_detect_decode((const float*)(ctx->arena + op.f32_off), op.f32_ld,
+                                              (float*)(ctx->arena + ctx->pred_off), n, ny, nx, ctx->na,
+                                              ctx->no, A, level_off, ctx->strides[op.level],
+                                              (const float*)(ctx->warena + ctx->anchors_off) + op.level * ctx->na * 2, s));
+            break;
+        }
+    }
+    return MDHIP_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char* mdhip_version(void) { return "mdhip 0.1 (gfx950, bf16)"; }
+
+const char* mdhip_last_error(mdhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch, int max_h,
+                 int max_w, mdhip_ctx** out) {
+    if (!out) return fail(nullptr, MDHIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!model || !model->layers || !model->convs || model->n_layers < 1)
+        return fail(nullptr, MDHIP_EINVAL, "empty model description");
+    if (dtype != MDHIP_DTYPE_BF16) return fail(nullptr, MDHIP_EUNSUPPORTED, "dtype %d not implemented (bf16 only)", dtype);
+    if (max_batch < 1 || max_h < 64 || max_w < 64) return fail(nullptr, MDHIP_EINVAL, "bad capacity %d x %dx%d", max_batch, max_h, max_w);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, MDHIP_EHIP, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, MDHIP_EINVAL, "device %d outside [0,%d)", device, ndev);
+
+    mdhip_ctx* ctx = new mdhip_ctx();
+    ctx->device = device;
+    ctx->dtype = dtype;
+    ctx->max_batch = max_batch;
+    ctx->nc = model->nc;
+    ctx->na = model->na;
+    ctx->nl = model->nl;
+    ctx->no = model->nc + 5;
+    bool has_detect = false;
+    for (int i = 0; i < model->n_layers; ++i) has_detect |= model->layers[i].type == MDHIP_DETECT;
+    ctx->max_stride = 2;
+    if (has_detect) {
+        if (model->nl < 1 || !model->strides || !model->anchors_px || model->nc < 1 || model->nc > 250) {
+            delete ctx;
+            return fail(nullptr, MDHIP_EINVAL, "Detect layer needs nl/strides/anchors/nc");
+        }
+        ctx->strides.assign(model->strides, model->strides + model->nl);
+        for (float s : ctx->strides) ctx->max_stride = std::max(ctx->max_stride, (int)s);
+    }
+    {   // largest stride of any layer (models without Detect, used by unit tests)
+        std::vector<int> div(model->n_layers, 1);
+        for (int i = 0; i < model->n_layers; ++i) {
+            const mdhip_layer& L = model->layers[i];
+            const int f0 = L.n_from > 0 ? L.from[0] : -1;
+            const int d = (f0 < 0 || f0 >= i) ? 1 : div[f0];
+            div[i] = L.type == MDHIP_CONV ? d * std::max(1, L.s) : (L.type == MDHIP_UPSAMPLE ? std::max(1, d / 2) : d);
+            ctx->max_stride = std::max(ctx->max_stride, div[i]);
+        }
+    }
+    ctx->max_h = round_up(max_h, ctx->max_stride);
+    ctx->max_w = round_up(max_w, ctx->max_stride);
+    ctx->layers.assign(model->layers, model->layers + model->n_layers);
+
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = conv_init();
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, MDHIP_EHIP, "device init failed: %s", hipGetErrorString(e));
+    }
+
+    Planner P;
+    P.ctx = ctx;
+    P.model = model;
+    if (!P.plan()) {
+        std::string msg = P.error;
+        delete ctx;
+        return fail(nullptr, MDHIP_EINVAL, "model planning failed: %s", msg.c_str());
+    }
+    // predictions, NMS scratch, letterbox geometry
+    ctx->a_max = has_detect ? num_anchors_for(ctx, ctx->max_h, ctx->max_w) : 1;
+    ctx->pred_off = P.alloc_bytes((size_t)max_batch * ctx->a_max * ctx->no * 4);
+    size_t nms_kv[4];
+    for (int i = 0; i < 4; ++i) nms_kv[i] = P.alloc_bytes((size_t)max_batch * ctx->a_max * 4);
+    ctx->nms_out_off = P.alloc_bytes((size_t)max_batch * kNmsMaxDet * 6 * 4);
+    ctx->nms_cnt_off = P.alloc_bytes((size_t)max_batch * 4);
+    ctx->geom_off = P.alloc_bytes((size_t)max_batch * sizeof(LetterboxDev));
+    ctx->arena_bytes = P.cursor + 256;
+
+    // weight arena
+    size_t wcur = 0;
+    ctx->zero_off = 0;
+    wcur = 256;
+    ctx->anchors_off = wcur;
+    wcur = align_up(wcur + (size_t)std::max(1, ctx->nl * ctx->na * 2) * 4, 256);
+    for (size_t i = 0; i < ctx->packed.size(); ++i) {
+        ctx->packed[i].w_off = wcur;
+        wcur = align_up(wcur + P.w_host[i].size() * 2, 256);
+        ctx->packed[i].b_off = wcur;
+        wcur = align_up(wcur + P.b_host[i].size() * 4, 256);
+    }
+    ctx->warena_bytes = wcur;
+
+#define CREATE_TRY(expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            std::string m = std::string(#expr) + " failed: " + hipGetErrorString(e__);          \
+            mdhip_destroy(ctx);                                                                 \
+            return fail(nullptr, e__ == hipErrorOutOfMemory ? MDHIP_ENOMEM : MDHIP_EHIP, "%s", m.c_str()); \
+        }                                                                                       \
+    } while (0)
+
+    CREATE_TRY(hipMalloc((void**)&ctx->arena, ctx->arena_bytes));
+    CREATE_TRY(hipMalloc((void**)&ctx->warena, ctx->warena_bytes));
+    CREATE_TRY(hipMemset(ctx->warena, 0, 256));
+    CREATE_TRY(hipMemset(ctx->arena, 0, std::min(ctx->arena_bytes, (size_t)1 << 20)));
+    if (has_detect)
+        CREATE_TRY(hipMemcpy(ctx->warena + ctx->anchors_off, model->anchors_px, (size_t)ctx->nl * ctx->na * 2 * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < ctx->packed.size(); ++i) {
+        CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].w_off, P.w_host[i].data(), P.w_host[i].size() * 2, hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].b_off, P.b_host[i].data(), P.b_host[i].size() * 4, hipMemcpyHostToDevice));
+    }
+    ctx->nms_scr.keys[0] = (uint32_t*)(ctx->arena + nms_kv[0]);
+    ctx->nms_scr.keys[1] = (uint32_t*)(ctx->arena + nms_kv[1]);
+    ctx->nms_scr.vals[0] = (uint32_t*)(ctx->arena + nms_kv[2]);
+    ctx->nms_scr.vals[1] = (uint32_t*)(ctx->arena + nms_kv[3]);
+    ctx->nms_scr.cap = ctx->a_max;
+    CREATE_TRY(hipDeviceSynchronize());
+#undef CREATE_TRY
+    *out = ctx;
+    return MDHIP_OK;
+}
+
+void mdhip_destroy(mdhip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->warena) (void)hipFree(ctx->warena);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    delete ctx;
+}
+
+int mdhip_max_stride(mdhip_ctx* ctx) { return ctx ? ctx->max_stride : MDHIP_EINVAL; }
+
+int mdhip_num_anchors(mdhip_ctx* ctx, int h, int w) {
+    if (!ctx) return MDHIP_EINVAL;
+    return num_anchors_for(ctx, h, w);
+}
+
+int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_letterbox* geom,
+                     int n, int out_h, int out_w, void* hip_stream) {
+    if (!ctx) return MDHIP_EINVAL;
+    if (!images || !geom) return fail(ctx, MDHIP_EINVAL, "images/geom is NULL");
+    if (int rc = check_shape(ctx, n, out_h, out_w)) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<LetterboxDev> g(n);
+    std::vector<bool> on_host(n);
+    size_t host_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const mdhip_letterbox& q = geom[i];
+        if (!images[i] || q.src_h < 1 || q.src_w < 1 || q.resized_h < 1 || q.resized_w < 1 || q.top < 0 || q.left < 0 ||
+            q.top + q.resized_h > out_h || q.left + q.resized_w > out_w)
+            return fail(ctx, MDHIP_EINVAL, "image %d: letterbox geometry does not fit %dx%d", i, out_h, out_w);
+        hipPointerAttribute_t attr;
+        const hipError_t e = hipPointerGetAttributes(&attr, images[i]);
+        bool host = true;
+        if (e == hipSuccess) host = !(attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+        else (void)hipGetLastError();
+        on_host[i] = host;
+        if (host) host_bytes += align_up((size_t)q.src_h * q.src_w * 3, 256);
+        g[i] = LetterboxDev{images[i], q.src_h, q.src_w, q.resized_h, q.resized_w, q.top, q.left};
+    }
+    if (host_bytes > ctx->stage_bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (ctx->stage) HIP_TRY(ctx, hipFree(ctx->stage));
+        ctx->stage = nullptr;
+        ctx->stage_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->stage, host_bytes));
+        ctx->stage_bytes = host_bytes;
+    }
+    size_t cur = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!on_host[i]) continue;
+        const size_t bytes = (size_t)g[i].src_h * g[i].src_w * 3;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->stage + cur, images[i], bytes, hipMemcpyHostToDevice, s));
+        g[i].src = (const uint8_t*)(ctx->stage + cur);
+        cur += align_up(bytes, 256);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena + ctx->geom_off, g.data(), n * sizeof(LetterboxDev), hipMemcpyHostToDevice, s));
+    // g is a stack-owned pageable buffer: the async copy above is staged synchronously by the runtime,
+    // but make that explicit so the vector may die safely.
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, launch_letterbox_s2d((const LetterboxDev*)(ctx->arena + ctx->geom_off), n, out_h, out_w,
+                                      (uint16_t*)(ctx->arena + ctx->input.off), s));
+    ctx->last_n = n;
+    ctx->last_h = out_h;
+    ctx->last_w = out_w;
+    return MDHIP_OK;
+}
+
+int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
+    if (!ctx) return MDHIP_EINVAL;
+    if (int rc = check_shape(ctx, n, h, w)) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (Op& op : ctx->ops)
+        if (int rc = run_op(ctx, op, n, h, w, s)) return rc;
+    ctx->last_n = n;
+    ctx->last_h = h;
+    ctx->last_w = w;
+    return MDHIP_OK;
+}
+
+int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hip_stream) {
+    if (!ctx || !ms) return MDHIP_EINVAL;
+    if (int rc = check_shape(ctx, n, h, w)) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t need = ctx->ops.size() + 1;
+    while (ctx->events.size() < need) {
+        hipEvent_t ev;
+        HIP_TRY(ctx, hipEventCreate(&ev));
+        ctx->events.push_back(ev);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->events[0], s));
+    for (size_t i = 0; i < ctx->ops.size(); ++i) {
+        if (int rc = run_op(ctx, ctx->ops[i], n, h, w, s)) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->events[i + 1], s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (size_t i = 0; i < ctx->ops.size(); ++i)
+        HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->events[i], ctx->events[i + 1]));
+    ctx->last_n = n;
+    ctx->last_h = h;
+    ctx->last_w = w;
+    return MDHIP_OK;
+}
+
+int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float* ms_avg, void* hip_stream) {
+    if (!ctx || !ms_avg || op < 0 || op >= (int)ctx->ops.size() || iters < 1) return MDHIP_EINVAL;
+    if (int rc = check_shape(ctx, n, h, w)) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    while (ctx->events.size() < 2) {
+        hipEvent_t ev;
+        HIP_TRY(ctx, hipEventCreate(&ev));
+        ctx->events.push_back(ev);
+    }
+    if (int rc = run_op(ctx, ctx->ops[op], n, h, w, s)) return rc;    // warm
+    HIP_TRY(ctx, hipEventRecord(ctx->events[0], s));
+    for (int i = 0; i < iters; ++i)
+        if (int rc = run_op(ctx, ctx->ops[op], n, h, w, s)) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->events[1], s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
+    *ms_avg = ms / iters;
+    return MDHIP_OK;
+}
+
+static int nms_common(mdhip_ctx* ctx, const float* pred_dev, int n, int n_anchors, float conf_thres,
+                      float iou_thres, int max_det, float* out, int32_t* counts, hipStream_t s) {
+    if (!out || !counts) return fail(ctx, MDHIP_EINVAL, "out/counts is NULL");
+    if (n < 1 || n > ctx->max_batch) return fail(ctx, MDHIP_EINVAL, "batch %d outside [1,%d]", n, ctx->max_batch);
+    if (max_det < 1 || max_det > kNmsMaxDet) return fail(ctx, MDHIP_EINVAL, "max_det %d outside [1,%d]", max_det, kNmsMaxDet);
+    if (n_anchors < 1 || n_anchors > ctx->a_max) return fail(ctx, MDHIP_EINVAL, "n_anchors %d outside [1,%d]", n_anchors, ctx->a_max);
+    float* out_dev = (float*)(ctx->arena + ctx->nms_out_off);
+    int* cnt_dev = (int*)(ctx->arena + ctx->nms_cnt_off);
+    HIP_TRY(ctx, launch_nms(pred_dev, n, n_anchors, ctx->no, conf_thres, iou_thres, max_det, ctx->nms_scr, out_dev, cnt_dev, s));
+    HIP_TRY(ctx, hipMemcpyAsync(out, out_dev, (size_t)n * max_det * 6 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(counts, cnt_dev, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MDHIP_OK;
+}
+
+int mdhip_nms(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_det, float* out,
+              int32_t* counts, void* hip_stream) {
+    if (!ctx) return MDHIP_EINVAL;
+    if (ctx->last_h == 0) return fail(ctx, MDHIP_EINVAL, "mdhip_nms before mdhip_forward");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int A = num_anchors_for(ctx, ctx->last_h, ctx->last_w);
+    return nms_common(ctx, (const float*)(ctx->arena + ctx->pred_off), n, A, conf_thres, iou_thres,
+                      max_det, out, counts, (hipStream_t)hip_stream);
+}
+
+int mdhip_nms_on(mdhip_ctx* ctx, const float* pred, int n, int n_anchors, float conf_thres,
+                 float iou_thres, int max_det, float* out, int32_t* counts, void* hip_stream) {
+    if (!ctx) return MDHIP_EINVAL;
+    if (!pred) return fail(ctx, MDHIP_EINVAL, "pred is NULL");
+    if (n < 1 || n > ctx->max_batch || n_anchors < 1 || n_anchors > ctx->a_max)
+        return fail(ctx, MDHIP_EINVAL, "n=%d n_anchors=%d outside the context capacity (%d x %d)", n, n_anchors, ctx->max_batch, ctx->a_max);
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* pred_dev = (float*)(ctx->arena + ctx->pred_off);
+    HIP_TRY(ctx, hipMemcpyAsync(pred_dev, pred, (size_t)n * n_anchors * ctx->no * 4, hipMemcpyHostToDevice, s));
+    return nms_common(ctx, pred_dev, n, n_anchors, conf_thres, iou_thres, max_det, out, counts, s);
+}
+
+int mdhip_read_predictions(mdhip_ctx* ctx, int n, float* out, void* hip_stream) {
+    if (!ctx || !out) return MDHIP_EINVAL;
+    if (ctx->last_h == 0 || n < 1 || n > ctx->last_n) return fail(ctx, MDHIP_EINVAL, "no forward result for n=%d", n);
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int A = num_anchors_for(ctx, ctx->last_h, ctx->last_w);
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->arena + ctx->pred_off, (size_t)n * A * ctx->no * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MDHIP_OK;
+}
+
+int mdhip_read_input(mdhip_ctx* ctx, int n, int h, int w, float* out, void* hip_stream) {
+    if (!ctx || !out) return MDHIP_EINVAL;
+    if (int rc = check_shape(ctx, n, h, w)) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    float* tmp = nullptr;
+    const size_t bytes = (size_t)n * 3 * h * w * 4;
+    HIP_TRY(ctx, hipMalloc((void**)&tmp, bytes));
+    hipError_t e = launch_s2d_to_nchw_f32((const uint16_t*)(ctx->arena + ctx->input.off), tmp, n, h, w, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    HIP_TRY(ctx, e);
+    return MDHIP_OK;
+}
+
+int mdhip_read_layer(mdhip_ctx* ctx, int layer, int n, float* out, int* c, int* h, int* w, void* hip_stream) {
+    if (!ctx) return MDHIP_EINVAL;
+    if (layer < 0 || layer >= (int)ctx->layer_out.size() || !ctx->layer_out[layer].valid)
+        return fail(ctx, MDHIP_EINVAL, "layer %d has no readable output", layer);
+    if (ctx->last_h == 0) return fail(ctx, MDHIP_EINVAL, "mdhip_read_layer before mdhip_forward");
+    const Tensor& t = ctx->layer_out[layer];
+    const int H = ctx->last_h / t.div, W = ctx->last_w / t.div;
+    if (c) *c = t.c;
+    if (h) *h = H;
+    if (w) *w = W;
+    if (!out) return MDHIP_OK;
+    if (n < 1 || n > ctx->last_n) return fail(ctx, MDHIP_EINVAL, "n=%d outside the last forward's batch %d", n, ctx->last_n);
+    hipStream_t s = (hipStream_t)hip_stream;
+    float* tmp = nullptr;
+    const size_t bytes = (size_t)n * t.c * H * W * 4;
+    HIP_TRY(ctx, hipMalloc((void**)&tmp, bytes));
+    hipError_t e = launch_nhwc_to_nchw_f32((const uint16_t*)(ctx->arena + t.off), t.ld, tmp, n, t.c, H, W, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    HIP_TRY(ctx, e);
+    return MDHIP_OK;
+}
+
+int mdhip_num_ops(mdhip_ctx* ctx) { return ctx ? (int)ctx->ops.size() : MDHIP_EINVAL; }
+
+int mdhip_get_op_info(mdhip_ctx* ctx, int op, mdhip_op_info* out) {
+    if (!ctx || !out || op < 0 || op >= (int)ctx->ops.size()) return MDHIP_EINVAL;
+    const Op& o = ctx->ops[op];
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", o.name.c_str());
+    out->kind = o.kind;
+    out->layer = o.layer;
+    out->m = o.gm;
+    out->n = o.gn;
+    out->k = o.gk;
+    out->flops = o.flops;
+    out->bytes = o.bytes;
+    out->cfg = o.last_cfg;
+    return MDHIP_OK;
+}
+
+int mdhip_num_conv_cfgs(void) { return conv_num_cfgs(); }
+
+int mdhip_set_op_cfg(mdhip_ctx* ctx, int op, int cfg) {
+    if (!ctx || op < 0 || op >= (int)ctx->ops.size()) return MDHIP_EINVAL;
+    if (ctx->ops[op].kind != OP_CONV) return fail(ctx, MDHIP_EINVAL, "op %d is not a conv", op);
+    if (cfg < -1 || cfg >= conv_num_cfgs()) return fail(ctx, MDHIP_EINVAL, "cfg %d outside [-1,%d)", cfg, conv_num_cfgs());
+    ctx->ops[op].forced_cfg = cfg;
+    return MDHIP_OK;
+}
+
+}  // extern "C"

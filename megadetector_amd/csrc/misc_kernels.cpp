@@ -1,0 +1,295 @@
+// HBM-bound kernels of the MDv5 hot path (gfx950): letterbox + normalise + space-to-depth,
+// SPPF max-pools, nearest upsample, Detect decode, and debug read-back helpers.
+//
+// Compiled with -ffp-contract=off: the fixed-point bilinear coordinates and the Detect
+// decode must round exactly like the un-fused NumPy / PyTorch expressions they replace.
+
+#include "mdhip_internal.h"
+
+namespace mdhip {
+
+// ---------------------------------------------------------------------------------------
+// letterbox_s2d: replaces  cv2.resize(INTER_LINEAR) + copyMakeBorder(114)  inside yolov5
+// letterbox() (reference pytorch_detector.py:1104-1109) and  transpose/float()/ /255
+// (reference pytorch_detector.py:1283-1306).
+//
+// Output layout: bf16 [n][out_h/2][out_w/2][16]; channel (dy*2+dx)*3 + c holds pixel
+// (2Y+dy, 2X+dx) colour c, channels 12..15 are zero.  In this space-to-depth form the model's
+// first layer (Conv 6x6 stride 2 pad 2 on 3 channels) is an ordinary 3x3 stride-1 pad-1
+// convolution on 16 channels, i.e. one more implicit-GEMM call with 32-byte pixels.
+//
+// Bilinear = OpenCV's 8-bit path: 11-bit coefficients, horizontal pass to int, vertical
+// pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void linear_coef(int d, int dst_len, int src_len, int& s0, int& s1,
+                                            int& w0, int& w1) {
+    const double scale = 1.0 / ((double)dst_len / (double)src_len);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src_len - 1) { f = 0.f; s = src_len - 1; }
+    w1 = __float2int_rn(f * 2048.0f);
+    w0 = __float2int_rn((1.0f - f) * 2048.0f);
+    s0 = s;
+    s1 = min(s + 1, src_len - 1);
+}
+
+__global__ void __launch_bounds__(256)
+letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w,
+                     uint16_t* __restrict__ out) {
+    const int img = blockIdx.z;
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;     // s2d column
+    const int Y = blockIdx.y;                                // s2d row
+    const int W2 = out_w >> 1, H2 = out_h >> 1;
+    if (X >= W2) return;
+    const LetterboxDev g = geom[img];
+    const bool resize = (g.resized_h != g.src_h) || (g.resized_w != g.src_w);
+
+    uint16_t px[16];
+#pragma unroll
+    for (int i = 12; i < 16; ++i) px[i] = 0;
+
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int y = 2 * Y + dy - g.top;
+        int y0 = 0, y1 = 0, b0 = 2048, b1 = 0;
+        const bool y_in = (unsigned)y < (unsigned)g.resized_h;
+        if (y_in && resize) linear_coef(y, g.resized_h, g.src_h, y0, y1, b0, b1);
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int x = 2 * X + dx - g.left;
+            int v[3] = {114, 114, 114};
+            if (y_in && (unsigned)x < (unsigned)g.resized_w) {
+                if (!resize) {
+                    const uint8_t* s = g.src + ((size_t)y * g.src_w + x) * 3;
+                    v[0] = s[0]; v[1] = s[1]; v[2] = s[2];
+                } else {
+                    int x0, x1, a0, a1;
+                    linear_coef(x, g.resized_w, g.src_w, x0, x1, a0, a1);
+                    const uint8_t* r0 = g.src + (size_t)y0 * g.src_w * 3;
+                    const uint8_t* r1 = g.src + (size_t)y1 * g.src_w * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int t0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+                        const int t1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+                        int o = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                        v[c] = min(max(o, 0), 255);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                px[(dy * 2 + dx) * 3 + c] = f32_to_bf16((float)v[c] / 255.0f);
+        }
+    }
+    uint4* dst = (uint4*)(out + (((size_t)img * H2 + Y) * W2 + X) * 16);
+    uint4 lo, hi;
+    lo.x = px[0] | ((uint32_t)px[1] << 16);   lo.y = px[2] | ((uint32_t)px[3] << 16);
+    lo.z = px[4] | ((uint32_t)px[5] << 16);   lo.w = px[6] | ((uint32_t)px[7] << 16);
+    hi.x = px[8] | ((uint32_t)px[9] << 16);   hi.y = px[10] | ((uint32_t)px[11] << 16);
+    hi.z = px[12] | ((uint32_t)px[13] << 16); hi.w = px[14] | ((uint32_t)px[15] << 16);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
+hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, int n, int out_h, int out_w,
+                                uint16_t* out, hipStream_t s) {
+    const int W2 = out_w / 2, H2 = out_h / 2;
+    dim3 grid((W2 + 255) / 256, H2, n);
+    hipLaunchKernelGGL(letterbox_s2d_kernel, grid, dim3(256), 0, s, geom_dev, out_h, out_w, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// 16-byte (8 x bf16) vector helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t max2_bf16(uint32_t a, uint32_t b) {
+    const float a0 = bf16_to_f32((uint16_t)(a & 0xffff)), a1 = bf16_to_f32((uint16_t)(a >> 16));
+    const float b0 = bf16_to_f32((uint16_t)(b & 0xffff)), b1 = bf16_to_f32((uint16_t)(b >> 16));
+    const uint32_t lo = (b0 > a0) ? (b & 0xffff) : (a & 0xffff);
+    const uint32_t hi = (b1 > a1) ? (b >> 16) : (a >> 16);
+    return lo | (hi << 16);
+}
+__device__ __forceinline__ uint4 max8_bf16(uint4 a, uint4 b) {
+    return make_uint4(max2_bf16(a.x, b.x), max2_bf16(a.y, b.y), max2_bf16(a.z, b.z), max2_bf16(a.w, b.w));
+}
+
+// ---------------------------------------------------------------------------------------
+// SPPF pools: y1 = maxpool k(x), y2 = maxpool k(y1), y3 = maxpool k(y2)  (stride 1, pad k/2,
+// -inf padding) == max over the (k), (2k-1), (3k-2) windows of x.  x is channel slice 0 of
+// buf, y1..y3 go to slices 1..3 (yolov5 models/common.py:SPPF.forward).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w, int r1) {
+    const long long total = (long long)n * h * w * c8;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int ch = (int)(t % c8);
+    long long pix = t / c8;
+    const int x = (int)(pix % w);
+    const int y = (int)((pix / w) % h);
+    const int b = (int)(pix / ((long long)w * h));
+    const int c = c8 * 8;
+    const uint16_t* base = buf + (size_t)b * h * w * ld + ch * 8;
+    const uint32_t ninf2 = 0xff80ff80u;   // two bf16 -inf
+    uint4 m1 = make_uint4(ninf2, ninf2, ninf2, ninf2), m2 = m1, m3 = m1;
+    const int r3 = 3 * r1, r2 = 2 * r1;
+    for (int dy = -r3; dy <= r3; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)h) continue;
+        const int ady = dy < 0 ? -dy : dy;
+        for (int dx = -r3; dx <= r3; ++dx) {
+            const int xx = x + dx;
+            if ((unsigned)xx >= (unsigned)w) continue;
+            const int adx = dx < 0 ? -dx : dx;
+            const uint4 v = *(const uint4*)(base + ((size_t)yy * w + xx) * ld);
+            m3 = max8_bf16(m3, v);
+            const int ad = ady > adx ? ady : adx;
+            if (ad <= r2) m2 = max8_bf16(m2, v);
+            if (ad <= r1) m1 = max8_bf16(m1, v);
+        }
+    }
+    uint16_t* o = buf + ((size_t)(b * h + y) * w + x) * ld + ch * 8;
+    *(uint4*)(o + c) = m1;
+    *(uint4*)(o + 2 * c) = m2;
+    *(uint4*)(o + 3 * c) = m3;
+}
+
+hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, int k, hipStream_t s) {
+    const long long total = (long long)n * h * w * (c / 8);
+    hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       buf, ld, c / 8, n, h, w, k / 2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// nearest x2 upsample (nn.Upsample(scale_factor=2, mode='nearest')) of a view into a view
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+upsample2x_kernel(const uint16_t* __restrict__ in, int ld_in, uint16_t* __restrict__ out, int ld_out,
+                  int c8, int n, int h, int w) {
+    const int ho = 2 * h, wo = 2 * w;
+    const long long total = (long long)n * ho * wo * c8;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int ch = (int)(t % c8);
+    long long pix = t / c8;
+    const int x = (int)(pix % wo);
+    const int y = (int)((pix / wo) % ho);
+    const int b = (int)(pix / ((long long)wo * ho));
+    const uint4 v = *(const uint4*)(in + ((size_t)(b * h + (y >> 1)) * w + (x >> 1)) * ld_in + ch * 8);
+    *(uint4*)(out + ((size_t)(b * ho + y) * wo + x) * ld_out + ch * 8) = v;
+}
+
+hipError_t launch_upsample2x(const uint16_t* in, int ld_in, uint16_t* out, int ld_out, int c,
+                             int n, int h, int w, hipStream_t s) {
+    const long long total = (long long)n * 4 * h * w * (c / 8);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       in, ld_in, out, ld_out, c / 8, n, h, w);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+copy_view_kernel(const uint16_t* __restrict__ in, int ld_in, uint16_t* __restrict__ out, int ld_out,
+                 int c8, long long pixels) {
+    const long long total = pixels * c8;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int ch = (int)(t % c8);
+    const long long pix = t / c8;
+    *(uint4*)(out + (size_t)pix * ld_out + ch * 8) = *(const uint4*)(in + (size_t)pix * ld_in + ch * 8);
+}
+
+hipError_t launch_copy_view(const uint16_t* in, int ld_in, uint16_t* out, int ld_out, int c,
+                            long long pixels, hipStream_t s) {
+    const long long total = pixels * (c / 8);
+    hipLaunchKernelGGL(copy_view_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       in, ld_in, out, ld_out, c / 8, pixels);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Detect decode (yolov5 models/yolo.py:Detect.forward, inference branch):
+//   y = sigmoid(logits);  xy = (y*2 + grid) * stride, grid = (x-0.5, y-0.5)
+//   wh = (y*2)^2 * anchor_px;  rows ordered (anchor, y, x) inside the level.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+detect_decode_kernel(const float* __restrict__ logits, int ld, float* __restrict__ pred, int n,
+                     int ny, int nx, int na, int no, int n_anchors, int level_off, float stride,
+                     const float* __restrict__ anchors_px) {
+    const long long total = (long long)n * na * ny * nx;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % nx);
+    const int y = (int)((t / nx) % ny);
+    const int a = (int)((t / ((long long)nx * ny)) % na);
+    const int b = (int)(t / ((long long)nx * ny * na));
+    const float* l = logits + ((size_t)(b * ny + y) * nx + x) * ld + a * no;
+    float* o = pred + ((size_t)b * n_anchors + level_off + (size_t)(a * ny + y) * nx + x) * no;
+    const float s0 = sigmoid_f32(l[0]), s1 = sigmoid_f32(l[1]);
+    const float s2 = sigmoid_f32(l[2]), s3 = sigmoid_f32(l[3]);
+    o[0] = (s0 * 2.0f + ((float)x - 0.5f)) * stride;
+    o[1] = (s1 * 2.0f + ((float)y - 0.5f)) * stride;
+    const float w2 = s2 * 2.0f, h2 = s3 * 2.0f;
+    o[2] = (w2 * w2) * anchors_px[a * 2 + 0];
+    o[3] = (h2 * h2) * anchors_px[a * 2 + 1];
+    for (int i = 4; i < no; ++i) o[i] = sigmoid_f32(l[i]);
+}
+
+hipError_t launch_detect_decode(const float* logits, int ld, float* pred, int n, int ny, int nx,
+                                int na, int no, int n_anchors, int level_off, float stride,
+                                const float* anchors_px, hipStream_t s) {
+    const long long total = (long long)n * na * ny * nx;
+    hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       logits, ld, pred, n, ny, nx, na, no, n_anchors, level_off, stride, anchors_px);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// debug read-back
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+nhwc_to_nchw_f32_kernel(const uint16_t* __restrict__ in, int ld, float* __restrict__ out, int n,
+                        int c, int h, int w) {
+    const long long total = (long long)n * c * h * w;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % w);
+    const int y = (int)((t / w) % h);
+    const int ch = (int)((t / ((long long)w * h)) % c);
+    const int b = (int)(t / ((long long)w * h * c));
+    out[t] = bf16_to_f32(in[((size_t)(b * h + y) * w + x) * ld + ch]);
+}
+
+hipError_t launch_nhwc_to_nchw_f32(const uint16_t* in, int ld, float* out, int n, int c, int h,
+                                   int w, hipStream_t s) {
+    const long long total = (long long)n * c * h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       s, in, ld, out, n, c, h, w);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+s2d_to_nchw_f32_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int n, int h, int w) {
+    const long long total = (long long)n * 3 * h * w;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % w);
+    const int y = (int)((t / w) % h);
+    const int ch = (int)((t / ((long long)w * h)) % 3);
+    const int b = (int)(t / ((long long)w * h * 3));
+    const int H2 = h / 2, W2 = w / 2;
+    out[t] = bf16_to_f32(in[(((size_t)b * H2 + (y >> 1)) * W2 + (x >> 1)) * 16 + ((y & 1) * 2 + (x & 1)) * 3 + ch]);
+}
+
+hipError_t launch_s2d_to_nchw_f32(const uint16_t* in, float* out, int n, int h, int w, hipStream_t s) {
+    const long long total = (long long)n * 3 * h * w;
+    hipLaunchKernelGGL(s2d_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       s, in, out, n, h, w);
+    return hipGetLastError();
+}
+
+}  // namespace mdhip

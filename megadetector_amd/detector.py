@@ -1,0 +1,264 @@
+"""
+HIPDetector: drop-in for the reference's PTDetector
+(megadetector/detection/pytorch_detector.py:739-1480) with the per-batch hot path running as
+hand-written HIP on one MI355X (libmdhip.so).
+
+Same constructor, same three public methods, same return dicts and failure conventions
+(SURVEY.md section 8(b)):
+  preprocess_image(img, image_id, image_size, verbose)            -> dict      (:964)
+  generate_detections_one_batch(imgs, ids, threshold, ...)        -> list[dict] (:1124)
+  generate_detections_one_image(img, id, threshold, ...)          -> dict      (:1428)
+
+Differences, all deliberate and documented in DESIGN.md:
+  * the letterbox resize runs on the GPU, so `preprocess_image` only computes the letterbox
+    geometry; 'img_processed' is a LetterboxSpec placeholder exposing `.shape` (dicts carrying
+    a real letterboxed ndarray, e.g. from the reference's own preprocessing workers, are
+    accepted too);
+  * only compatibility_mode 'classic' (the reference default) is implemented;
+  * augment=True (TTA) is not implemented and raises, which the caller sees as
+    FAILURE_INFER for that batch, exactly like any other inference exception.
+"""
+
+import numpy as np
+
+from . import weights_io
+from .constants import (FAILURE_IMAGE_OPEN, FAILURE_INFER, DEFAULT_COMPATIBILITY_MODE)
+from .postprocess import letterbox_geometry, format_detections
+
+
+def parse_bool_string(s):
+    """reference megadetector/utils/ct_utils.py:1000"""
+    if isinstance(s, bool):
+        return s
+    s = str(s).lower().strip()
+    if s in ('true', '1', 'yes', 'y'):
+        return True
+    if s in ('false', '0', 'no', 'n'):
+        return False
+    raise ValueError('Cannot convert "{}" to bool'.format(s))
+
+
+class LetterboxSpec:
+    """Placeholder for the letterboxed image: the pixels are produced on the GPU."""
+
+    __slots__ = ('shape', 'geometry')
+
+    def __init__(self, shape, geometry):
+        self.shape = tuple(shape)
+        self.geometry = tuple(geometry)    # (src_h, src_w, resized_h, resized_w, top, left)
+
+    def __reduce__(self):
+        return (LetterboxSpec, (self.shape, self.geometry))
+
+
+def _device_ordinal(device):
+    s = str(device).lower()
+    if s.startswith('cuda'):
+        return int(s.split(':')[1]) if ':' in s else 0
+    raise ValueError('HIPDetector needs a GPU device ("cuda:N"), got {}'.format(device))
+
+
+class HIPDetector:
+
+    def __init__(self, model_path, detector_options=None, verbose=False):
+        """
+        model_path: a YOLOv5 .pt checkpoint (md_v5a.0.0.pt ...), a YoloWeights object, or the
+        string 'synthetic[:yaml_name[:seed]]' for seeded weights on the MDv5 topology.
+        detector_options keys honoured: force_cpu (must be false), use_model_native_classes,
+        compatibility_mode, preprocess_only, device, batch_size, max_image_size.
+        """
+        opts = dict(detector_options or {})
+        self.use_model_native_classes = parse_bool_string(opts.get('use_model_native_classes', False))
+        compat = opts.get('compatibility_mode') or DEFAULT_COMPATIBILITY_MODE
+        self.compatibility_mode = compat
+        preprocess_only = bool(opts.get('preprocess_only', False))
+        if verbose or not preprocess_only:
+            print('Loading HIP detector with compatibility mode {}'.format(compat))
+        if 'classic' not in compat:
+            raise ValueError('HIPDetector implements compatibility_mode "classic" only (got {})'.format(compat))
+
+        self.model_metadata = None
+        if isinstance(model_path, str) and not model_path.startswith('synthetic'):
+            self.model_metadata = weights_io.read_metadata_from_megadetector_model_file(model_path)
+        if self.model_metadata is not None and 'image_size' in self.model_metadata:
+            self.default_image_size = self.model_metadata['image_size']
+            print('Loaded image size {} from model metadata'.format(self.default_image_size))
+        else:
+            # reference pytorch_detector.py:802-805
+            if not preprocess_only:
+                print('No image size available in model metadata, defaulting to 1280')
+            self.default_image_size = 1280
+        self.device = 'cpu'
+        self.printed_image_size_warning = False
+        # reference :827-845
+        self.letterbox_stride = 64 if self.default_image_size == 1280 else 32
+        self.half_precision = False
+        self.model = None
+        self._ctx = None
+        if preprocess_only:
+            return                      # never touches HIP: safe in forked producer processes
+
+        if parse_bool_string(opts.get('force_cpu', False)):
+            raise RuntimeError('HIPDetector has no CPU path (force_cpu requested)')
+        device = opts.get('device') or 'cuda:0'
+        self.device = device
+        # AddaxAI parses this line from the reference (pytorch_detector.py:885)
+        print('PTDetector using device {}'.format(str(self.device).lower()))
+
+        if isinstance(model_path, str):
+            if model_path.startswith('synthetic'):
+                parts = model_path.split(':')
+                from . import yolo_yaml
+                yaml = getattr(yolo_yaml, parts[1]) if len(parts) > 1 and parts[1] else yolo_yaml.YOLOV5X6_MD
+                seed = int(parts[2]) if len(parts) > 2 else 0
+                weights = weights_io.synthetic_weights(yaml, seed=seed)
+            else:
+                weights = weights_io.load_checkpoint(model_path)
+        else:
+            weights = model_path
+        self.weights = weights
+        if weights.max_stride != self.letterbox_stride and verbose:
+            print('*** Warning: model stride is {}, letterbox stride is {} ***'.format(
+                weights.max_stride, self.letterbox_stride))
+        from .hip_backend import HipContext
+        self.max_batch = int(opts.get('batch_size', 1)) if int(opts.get('batch_size', 1)) > 1 else int(opts.get('max_batch', 8))
+        max_size = int(opts.get('max_image_size', self.default_image_size))
+        max_size = -(-max_size // weights.max_stride) * weights.max_stride
+        self._ctx = HipContext(weights, device=_device_ordinal(device), dtype=opts.get('dtype', 'bf16'),
+                               max_batch=self.max_batch, max_h=max_size, max_w=max_size)
+        self.model = self._ctx
+
+    # -----------------------------------------------------------------------------------
+    def preprocess_image(self, img_original, image_id='unknown', image_size=None, verbose=False):
+        """reference pytorch_detector.py:964-1119 ('classic'): geometry only, pixels stay put."""
+        result = {'file': image_id}
+        img_original_pil = None
+        if not isinstance(img_original, np.ndarray):
+            img_original_pil = img_original
+            img_original = np.asarray(img_original)
+        if img_original.ndim != 3 or img_original.shape[2] != 3 or img_original.dtype != np.uint8:
+            raise ValueError('expected an HxWx3 uint8 RGB image, got {} {}'.format(
+                img_original.shape, img_original.dtype))
+        scaling_shape = img_original.shape
+        if image_size is not None:
+            assert isinstance(image_size, int)
+            if not self.printed_image_size_warning:
+                print('Using user-supplied image size {}'.format(image_size))
+                self.printed_image_size_warning = True
+        else:
+            image_size = self.default_image_size
+            self.printed_image_size_warning = False
+        g = letterbox_geometry(img_original.shape[:2], new_shape=image_size, stride=self.letterbox_stride,
+                               auto=True, scaleup=True)
+        geometry = (img_original.shape[0], img_original.shape[1], g['new_unpad'][1], g['new_unpad'][0],
+                    g['top'], g['left'])
+        result['img_processed'] = LetterboxSpec((g['out_hw'][0], g['out_hw'][1], 3), geometry)
+        result['img_original'] = img_original
+        result['img_original_pil'] = img_original_pil
+        result['target_shape'] = image_size
+        result['scaling_shape'] = scaling_shape
+        result['letterbox_ratio'] = g['ratio']
+        result['letterbox_pad'] = g['pad']
+        return result
+
+    # -----------------------------------------------------------------------------------
+    def generate_detections_one_batch(self, img_original, image_id=None, detection_threshold=0.00001,
+                                      image_size=None, augment=False, verbose=False):
+        """reference pytorch_detector.py:1124-1252"""
+        if not isinstance(img_original, list):
+            raise ValueError('img_original must be a list for batch processing')
+        if len(img_original) == 0:
+            return []
+        if isinstance(img_original[0], dict):
+            for i, img in enumerate(img_original):
+                if not isinstance(img, dict):
+                    raise ValueError('Mixed input types in batch: item {} is not a dict, but item 0 is a dict'.format(i))
+        else:
+            if image_id is None:
+                raise ValueError('image_id must be a list when img_original contains PIL/numpy images')
+            if not isinstance(image_id, list):
+                raise ValueError('image_id must be a list for batch processing')
+            if len(image_id) != len(img_original):
+                raise ValueError('Length mismatch: img_original has {} items, image_id has {} items'.format(
+                    len(img_original), len(image_id)))
+            for i_img, img in enumerate(img_original):
+                if isinstance(img, dict):
+                    raise ValueError('Mixed input types in batch: item {} is a dict, but item 0 is not a dict'.format(i_img))
+        if detection_threshold is None:
+            detection_threshold = 0.0
+        if self._ctx is None:
+            raise RuntimeError('this HIPDetector was created with preprocess_only')
+
+        results = [None] * len(img_original)
+        preprocessed = []
+        for i_img, img in enumerate(img_original):
+            try:
+                if isinstance(img, dict):
+                    info = img
+                    current_id = info['file']
+                else:
+                    current_id = image_id[i_img]
+                    info = self.preprocess_image(img, image_id=current_id, image_size=image_size, verbose=verbose)
+                preprocessed.append((i_img, info, current_id))
+            except Exception as e:
+                current_id = image_id[i_img] if image_id else 'index_{}'.format(i_img)
+                print('Warning: preprocessing failed for image {}: {}'.format(current_id, str(e)))
+                results[i_img] = {'file': current_id, 'detections': None, 'failure': FAILURE_IMAGE_OPEN}
+
+        shape_groups = {}
+        for item in preprocessed:
+            shape_groups.setdefault(tuple(item[1]['img_processed'].shape), []).append(item)
+
+        for shape, items in shape_groups.items():
+            try:
+                for start in range(0, len(items), self.max_batch):
+                    self._process_batch_group(items[start:start + self.max_batch], results,
+                                              detection_threshold, augment, verbose)
+            except Exception as e:
+                print('Warning: batch inference failed for shape {}: {}'.format(shape, str(e)))
+                for original_idx, _, current_id in items:
+                    results[original_idx] = {'file': current_id, 'detections': None, 'failure': FAILURE_INFER}
+        return results
+
+    def _process_batch_group(self, group_items, results, detection_threshold, augment, verbose):
+        """reference pytorch_detector.py:1257-1426 with the device work in libmdhip.so"""
+        if len(group_items) == 0:
+            return
+        if augment:
+            raise NotImplementedError('test-time augmentation is not implemented in the HIP path')
+        h, w = group_items[0][1]['img_processed'].shape[:2]
+        images, geoms = [], []
+        for _, info, _ in group_items:
+            ip = info['img_processed']
+            if isinstance(ip, LetterboxSpec):
+                images.append(np.ascontiguousarray(info['img_original']))
+                geoms.append(ip.geometry)
+            else:                      # an already letterboxed HWC u8 array
+                ip = np.ascontiguousarray(ip)
+                images.append(ip)
+                geoms.append((ip.shape[0], ip.shape[1], ip.shape[0], ip.shape[1], 0, 0))
+        n = len(group_items)
+        ctx = self._ctx
+        ctx.preprocess(images, geoms, h, w)
+        ctx.forward(n, h, w)
+        nms_iou_thres = 0.45            # 'classic' (reference :1318-1321)
+        det_all, counts = ctx.nms(n, detection_threshold, nms_iou_thres, max_det=300)
+        for i, (original_idx, info, current_id) in enumerate(group_items):
+            det = det_all[i, :counts[i]]
+            detections, max_conf = format_detections(
+                det, (h, w), info['img_original'].shape, info['scaling_shape'], detection_threshold,
+                use_model_native_classes=self.use_model_native_classes)
+            results[original_idx] = {'file': current_id, 'detections': detections,
+                                     'max_detection_conf': max_conf}
+
+    # -----------------------------------------------------------------------------------
+    def generate_detections_one_image(self, img_original, image_id='unknown', detection_threshold=0.00001,
+                                      image_size=None, augment=False, verbose=False):
+        """reference pytorch_detector.py:1428-1478"""
+        if isinstance(img_original, dict):
+            res = self.generate_detections_one_batch([img_original], None, detection_threshold,
+                                                     image_size, augment, verbose)
+        else:
+            res = self.generate_detections_one_batch([img_original], [image_id], detection_threshold,
+                                                     image_size, augment, verbose)
+        return res[0]

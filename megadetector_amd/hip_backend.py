@@ -1,0 +1,186 @@
+"""
+Thin Python owner of one mdhip context (one GPU): turns YoloWeights into the C model
+description, and exposes the hot-path stages with numpy in / numpy out.
+All arithmetic happens in libmdhip.so (hand-written HIP); nothing here computes.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import HipError
+from .yolo_model import MDHIP_DETECT
+
+
+class HipContext:
+
+    def __init__(self, weights, device=0, dtype='bf16', max_batch=32, max_h=1280, max_w=1280):
+        self.lib = _lib.load()
+        self.weights = weights
+        self.device = int(device)
+        self.max_batch = int(max_batch)
+        self._keep = []
+        specs = weights.specs
+        convs = []
+        layers = (_lib.mdhip_layer * len(specs))()
+        for i, s in enumerate(specs):
+            L = layers[i]
+            L.type = s.type
+            L.n_from = len(s.frm)
+            for j, f in enumerate(s.frm):
+                L.from_[j] = f
+            L.c_out = s.c_out if s.c_out is not None else 0
+            L.k, L.s, L.p = s.k or 0, s.s or 1, s.p or 0
+            L.n = s.n or 1
+            L.shortcut = s.shortcut or 0
+            L.first_conv = len(convs)
+            for name in s.conv_names:
+                w = weights.weights[name + '.weight']
+                b = weights.weights[name + '.bias']
+                self._keep += [w, b]
+                cv = _lib.mdhip_conv()
+                cv.weight = w.ctypes.data_as(C.POINTER(C.c_float))
+                cv.bias = b.ctypes.data_as(C.POINTER(C.c_float))
+                cv.c_out, cv.c_in, cv.kh, cv.kw = w.shape
+                convs.append(cv)
+        conv_arr = (_lib.mdhip_conv * max(1, len(convs)))(*convs)
+        m = _lib.mdhip_model()
+        m.n_layers = len(specs)
+        m.layers = layers
+        m.n_convs = len(convs)
+        m.convs = conv_arr
+        m.nc = weights.nc
+        m.na = weights.na
+        m.nl = weights.nl
+        anchors = np.ascontiguousarray(weights.anchors_px.reshape(-1), dtype=np.float32)
+        strides = np.ascontiguousarray(np.asarray(weights.strides, dtype=np.float32))
+        self._keep += [anchors, strides, layers, conv_arr]
+        m.anchors_px = anchors.ctypes.data_as(C.POINTER(C.c_float)) if anchors.size else None
+        m.strides = strides.ctypes.data_as(C.POINTER(C.c_float)) if strides.size else None
+        dt = {'bf16': _lib.MDHIP_DTYPE_BF16, 'fp8': _lib.MDHIP_DTYPE_FP8}[dtype]
+        handle = C.c_void_p()
+        rc = self.lib.mdhip_create(C.byref(m), self.device, dt, int(max_batch), int(max_h), int(max_w),
+                                   C.byref(handle))
+        if rc != 0:
+            raise HipError('mdhip_create failed ({}): {}'.format(
+                rc, self.lib.mdhip_last_error(None).decode()))
+        self.h = handle
+        self.no = weights.nc + 5
+        self.has_detect = specs[-1].type == MDHIP_DETECT
+        self.max_stride = self.lib.mdhip_max_stride(self.h)
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise HipError('{} failed ({}): {}'.format(what, rc, self.lib.mdhip_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h.value:
+            self.lib.mdhip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- hot path ---------------------------------------------------------------------
+    def preprocess(self, images, geoms, out_h, out_w, stream=0):
+        """
+        images: list of HWC uint8 RGB numpy arrays (host) or integer device pointers.
+        geoms:  list of (src_h, src_w, resized_h, resized_w, top, left).
+        """
+        n = len(images)
+        ptrs = (C.c_void_p * n)()
+        hold = []
+        for i, im in enumerate(images):
+            if isinstance(im, np.ndarray):
+                if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                    raise ValueError('image {} must be HWC uint8 RGB'.format(i))
+                im = np.ascontiguousarray(im)
+                hold.append(im)
+                ptrs[i] = im.ctypes.data
+            else:
+                ptrs[i] = int(im)
+        g = (_lib.mdhip_letterbox * n)()
+        for i, q in enumerate(geoms):
+            g[i].src_h, g[i].src_w, g[i].resized_h, g[i].resized_w, g[i].top, g[i].left = [int(v) for v in q]
+        self._check(self.lib.mdhip_preprocess(self.h, C.cast(ptrs, C.POINTER(C.c_void_p)), g, n, int(out_h), int(out_w),
+                                              C.c_void_p(stream)), 'mdhip_preprocess')
+
+    def forward(self, n, h, w, stream=0):
+        self._check(self.lib.mdhip_forward(self.h, int(n), int(h), int(w), C.c_void_p(stream)), 'mdhip_forward')
+
+    def nms(self, n, conf_thres, iou_thres, max_det=300, stream=0):
+        out = np.empty((n, max_det, 6), dtype=np.float32)
+        counts = np.empty((n,), dtype=np.int32)
+        self._check(self.lib.mdhip_nms(self.h, int(n), float(conf_thres), float(iou_thres), int(max_det),
+                                       _lib.np_ptr(out), _lib.np_ptr(counts), C.c_void_p(stream)), 'mdhip_nms')
+        return out, counts
+
+    def nms_on(self, pred, conf_thres, iou_thres, max_det=300, stream=0):
+        pred = np.ascontiguousarray(pred, dtype=np.float32)
+        n, a, no = pred.shape
+        if no != self.no:
+            raise ValueError('prediction width {} != {}'.format(no, self.no))
+        out = np.empty((n, max_det, 6), dtype=np.float32)
+        counts = np.empty((n,), dtype=np.int32)
+        self._check(self.lib.mdhip_nms_on(self.h, _lib.np_ptr(pred), n, a, float(conf_thres), float(iou_thres),
+                                          int(max_det), _lib.np_ptr(out), _lib.np_ptr(counts),
+                                          C.c_void_p(stream)), 'mdhip_nms_on')
+        return out, counts
+
+    # -- introspection ------------------------------------------------------------------
+    def num_anchors(self, h, w):
+        return self.lib.mdhip_num_anchors(self.h, int(h), int(w))
+
+    def read_predictions(self, n, h, w, stream=0):
+        out = np.empty((n, self.num_anchors(h, w), self.no), dtype=np.float32)
+        self._check(self.lib.mdhip_read_predictions(self.h, n, _lib.np_ptr(out), C.c_void_p(stream)),
+                    'mdhip_read_predictions')
+        return out
+
+    def read_input(self, n, h, w, stream=0):
+        out = np.empty((n, 3, h, w), dtype=np.float32)
+        self._check(self.lib.mdhip_read_input(self.h, n, h, w, _lib.np_ptr(out), C.c_void_p(stream)), 'mdhip_read_input')
+        return out
+
+    def read_layer(self, layer, n, stream=0):
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.mdhip_read_layer(self.h, layer, n, None, C.byref(c), C.byref(h), C.byref(w),
+                                              C.c_void_p(stream)), 'mdhip_read_layer')
+        out = np.empty((n, c.value, h.value, w.value), dtype=np.float32)
+        self._check(self.lib.mdhip_read_layer(self.h, layer, n, _lib.np_ptr(out), C.byref(c), C.byref(h),
+                                              C.byref(w), C.c_void_p(stream)), 'mdhip_read_layer')
+        return out
+
+    def num_ops(self):
+        return self.lib.mdhip_num_ops(self.h)
+
+    def op_infos(self):
+        res = []
+        for i in range(self.num_ops()):
+            info = _lib.mdhip_op_info()
+            self._check(self.lib.mdhip_get_op_info(self.h, i, C.byref(info)), 'mdhip_get_op_info')
+            res.append(dict(op=i, name=info.name.decode(), kind=info.kind, layer=info.layer, m=info.m,
+                            n=info.n, k=info.k, flops=info.flops, bytes=info.bytes, cfg=info.cfg))
+        return res
+
+    def forward_timed(self, n, h, w, stream=0):
+        ms = np.zeros((self.num_ops(),), dtype=np.float32)
+        self._check(self.lib.mdhip_forward_timed(self.h, n, h, w, _lib.np_ptr(ms), C.c_void_p(stream)),
+                    'mdhip_forward_timed')
+        return ms
+
+    def set_op_cfg(self, op, cfg):
+        self._check(self.lib.mdhip_set_op_cfg(self.h, op, cfg), 'mdhip_set_op_cfg')
+
+    def num_conv_cfgs(self):
+        return self.lib.mdhip_num_conv_cfgs()
+
+    def time_op(self, op, n, h, w, iters=10, stream=0):
+        ms = C.c_float()
+        self._check(self.lib.mdhip_time_op(self.h, op, n, h, w, iters, C.byref(ms), C.c_void_p(stream)), 'mdhip_time_op')
+        return ms.value

@@ -1,0 +1,86 @@
+"""CPU-side checks of the drop-in boundary: the shared library builds, loads and exports every
+symbol include/mdhip.h declares; without a GPU the product path fails loudly (no fallback)."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def _header_symbols():
+    text = open(os.path.join(REPO, 'include', 'mdhip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mdhip_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as G
+    G.build()
+    from megadetector_amd import _lib
+    lib = _lib.load()
+    declared = _header_symbols()
+    assert declared, 'no symbols parsed from include/mdhip.h'
+    for name in declared:
+        assert hasattr(lib, name), 'libmdhip.so does not export {}'.format(name)
+    assert sorted(_lib.SYMBOLS) == declared, 'ctypes table and header disagree'
+    assert b'gfx950' in lib.mdhip_version()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd._lib import HipError
+    from megadetector_amd.detector import HIPDetector
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5N6_TEST, seed=1)
+    with pytest.raises(HipError, match='no HIP device'):
+        HIPDetector(W, {'batch_size': 2, 'max_image_size': 256})
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        HIPDetector(W, {'force_cpu': 'true'})
+
+
+def test_preprocess_only_instance_never_touches_hip_and_pickles():
+    import pickle
+    from megadetector_amd.detector import HIPDetector
+    from oracle import pre_post as O
+    d = HIPDetector('synthetic', {'preprocess_only': True})
+    rng = np.random.default_rng(0)
+    for shape in [(1536, 2048), (1080, 1920), (1280, 1280), (600, 901), (2448, 3264)]:
+        img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+        r = d.preprocess_image(img, 'x.jpg')
+        g = O.letterbox_geometry(shape, 1280, 64)
+        assert r['img_processed'].shape == g['out_hw'] + (3,)
+        assert r['letterbox_ratio'] == g['ratio'] and r['letterbox_pad'] == g['pad']
+        assert r['img_processed'].geometry == (shape[0], shape[1], g['new_unpad'][1], g['new_unpad'][0], g['top'], g['left'])
+        assert r['scaling_shape'] == img.shape and r['target_shape'] == 1280
+        rr = pickle.loads(pickle.dumps(r))
+        assert rr['img_processed'].shape == r['img_processed'].shape
+    with pytest.raises(RuntimeError):
+        d.generate_detections_one_batch([img], ['x.jpg'])
+
+
+def test_postprocess_matches_reference_statements():
+    """vectorised host formatting == the reference's per-detection loop (restated in the oracle)"""
+    import torch
+    from megadetector_amd.postprocess import format_detections
+    from oracle import pre_post as O
+    rng = np.random.default_rng(3)
+    for (h0, w0), (h1, w1) in [((1536, 2048), (960, 1280)), ((1080, 1920), (768, 1280)),
+                               ((1280, 1280), (1280, 1280)), ((333, 517), (832, 1280))]:
+        k = 120
+        x1 = rng.random(k) * w1 * 0.8
+        y1 = rng.random(k) * h1 * 0.8
+        det = np.stack([x1 - 20, y1 - 20, x1 + rng.random(k) * 400, y1 + rng.random(k) * 300,
+                        np.sort(rng.random(k) ** 3)[::-1], rng.integers(0, 3, k)], 1).astype(np.float32)
+        for thr in (1e-5, 0.005, 0.2):
+            got, gmax = format_detections(det, (h1, w1), (h0, w0, 3), (h0, w0, 3), thr)
+            ref, rmax = O.format_detections(torch.from_numpy(det), (h1, w1), (h0, w0, 3), (h0, w0, 3), thr)
+            assert got == ref and gmax == rmax
+    assert format_detections(np.zeros((0, 6), np.float32), (64, 64), (64, 64, 3), (64, 64, 3), 0.1) == ([], 0.0)
+    bad = np.array([[0, 0, 10, 10, 0.9, 7]], dtype=np.float32)
+    with pytest.raises(KeyError):
+        format_detections(bad, (64, 64), (64, 64, 3), (64, 64, 3), 0.1)

@@ -1,0 +1,233 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): every stage of the HIP hot path, called
+through the C ABI (include/mdhip.h via megadetector_amd.hip_backend), against the CPU oracle
+on the same seeded inputs, against the committed golden fixtures, and -- at full size --
+through size-independent properties.
+
+Tolerances (stated once, used below):
+  * integer / byte / index work (letterbox + resize, NMS selection and order, categories):
+    bit-exact.
+  * conv stack vs the bf16-emulating oracle (same storage rounding, different fp32 summation
+    order): max|err| <= 3e-2 * max|ref| and mean|err| <= 4e-3 * mean|ref| per layer.
+  * predictions vs the fp32 oracle (what the reference computes): reported; end-to-end
+    detections must satisfy the reference's own pass bar (md_tests.py:96-100):
+    |dconf| <= 0.005, |dcoord| <= 0.001 after matching at IoU >= 0.85.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+import parity_util as PU
+from oracle import pre_post as O
+
+pytestmark = pytest.mark.gpu
+
+LAYER_MAX_TOL = 3e-2
+LAYER_MEAN_TOL = 4e-3
+
+
+@pytest.fixture(scope='module')
+def n6():
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5N6_TEST, seed=1)
+    ctx = HipContext(W, device=0, max_batch=4, max_h=320, max_w=320)
+    yield W, ctx
+    ctx.close()
+
+
+def _identity_geoms(images):
+    return [(im.shape[0], im.shape[1], im.shape[0], im.shape[1], 0, 0) for im in images]
+
+
+# ---------------------------------------------------------------------------------------
+# preprocess: bit-exact
+# ---------------------------------------------------------------------------------------
+def test_preprocess_identity_bit_exact(n6):
+    W, ctx = n6
+    imgs = PU.random_images(3, 256, 192, seed=3)
+    ctx.preprocess(imgs, _identity_geoms(imgs), 256, 192)
+    got = ctx.read_input(3, 256, 192)
+    ref = PU.bf16_round_np(O.to_batch_tensor(imgs).numpy())
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize('shape', [(300, 400), (97, 211), (640, 360), (1000, 750), (128, 128)])
+def test_preprocess_letterbox_resize_bit_exact(n6, shape):
+    from megadetector_amd.postprocess import letterbox_geometry
+    W, ctx = n6
+    imgs = PU.structured_images(2, shape[0], shape[1], seed=shape[0])
+    g = letterbox_geometry(shape, new_shape=256, stride=64)
+    geoms = [(shape[0], shape[1], g['new_unpad'][1], g['new_unpad'][0], g['top'], g['left'])] * 2
+    h, w = g['out_hw']
+    ctx.preprocess(imgs, geoms, h, w)
+    got = ctx.read_input(2, h, w)
+    x, infos = PU.oracle_input(imgs, 256, 64)
+    assert tuple(x.shape[2:]) == (h, w)
+    np.testing.assert_array_equal(got, PU.bf16_round_np(x.numpy()))
+
+
+# ---------------------------------------------------------------------------------------
+# conv stack: layer by layer against the bf16-emulating oracle
+# ---------------------------------------------------------------------------------------
+def test_every_layer_matches_bf16_oracle(n6):
+    W, ctx = n6
+    imgs = PU.structured_images(2, 256, 256, seed=5)
+    ctx.preprocess(imgs, _identity_geoms(imgs), 256, 256)
+    ctx.forward(2, 256, 256)
+    x, _ = PU.oracle_input(imgs, 256, 64)
+    keep = {}
+    pred_ref, _ = PU.oracle_forward(W, x, emulate_bf16=True, keep=keep)
+    worst = []
+    for i in sorted(keep):
+        got = ctx.read_layer(i, 2)
+        emax, emean = PU.rel_err(got, keep[i].numpy())
+        worst.append((i, emax, emean))
+    bad = [t for t in worst if t[1] > LAYER_MAX_TOL or t[2] > LAYER_MEAN_TOL]
+    assert not bad, 'layers out of tolerance (layer, max, mean): {}'.format(bad)
+    pred = ctx.read_predictions(2, 256, 256)
+    assert pred.shape == tuple(pred_ref.shape)
+    emax, emean = PU.rel_err(pred[..., :4], pred_ref[..., :4].numpy())
+    assert emax < 2e-2 and emean < 4e-3
+    assert np.abs(pred[..., 4:] - pred_ref[..., 4:].numpy()).max() < 2e-2
+
+
+def test_tile_configurations_agree_bitwise(n6):
+    """Every tile configuration accumulates K in the same order: outputs must be identical."""
+    W, ctx = n6
+    imgs = PU.random_images(2, 192, 256, seed=8)
+    ctx.preprocess(imgs, _identity_geoms(imgs), 192, 256)
+    ctx.forward(2, 192, 256)
+    base = ctx.read_predictions(2, 192, 256).copy()
+    convs = [o['op'] for o in ctx.op_infos() if o['kind'] == 0]
+    try:
+        for cfg in range(ctx.num_conv_cfgs()):
+            for op in convs:
+                ctx.set_op_cfg(op, cfg)
+            ctx.forward(2, 192, 256)
+            got = ctx.read_predictions(2, 192, 256)
+            np.testing.assert_array_equal(got, base, err_msg='cfg {}'.format(cfg))
+    finally:
+        for op in convs:
+            ctx.set_op_cfg(op, -1)
+
+
+def test_batch_composition_invariance(n6):
+    """reference md_tests.py:1235-1238: batched == unbatched (here: bit-identical)."""
+    W, ctx = n6
+    imgs = PU.random_images(4, 256, 256, seed=11)
+    ctx.preprocess(imgs, _identity_geoms(imgs), 256, 256)
+    ctx.forward(4, 256, 256)
+    full = ctx.read_predictions(4, 256, 256).copy()
+    for i in (0, 3):
+        ctx.preprocess([imgs[i]], _identity_geoms([imgs[i]]), 256, 256)
+        ctx.forward(1, 256, 256)
+        np.testing.assert_array_equal(ctx.read_predictions(1, 256, 256)[0], full[i])
+
+
+# ---------------------------------------------------------------------------------------
+# NMS: bit-exact against the reference fixtures and the oracle
+# ---------------------------------------------------------------------------------------
+def _canon(a):
+    a = np.asarray(a, dtype=np.float32)
+    if a.shape[0] == 0:
+        return a
+    return a[np.lexsort((a[:, 5], a[:, 3], a[:, 2], a[:, 1], a[:, 0], -a[:, 4]))]
+
+
+@pytest.mark.parametrize('case', ['synthetic', 'identical', 'rand_a', 'rand_b', 'rand_c', 'empty'])
+def test_nms_matches_reference_fixture(n6, case):
+    W, ctx = n6
+    blob = np.load(os.path.join(GOLDEN, 'nms_reference.npz'))
+    pred = blob[case + '/pred']
+    ct, it, md = blob[case + '/params']
+    out, counts = ctx.nms_on(pred, float(ct), float(it), int(md))
+    for i in range(pred.shape[0]):
+        ref = blob['{}/out{}'.format(case, i)]
+        assert counts[i] == ref.shape[0]
+        np.testing.assert_array_equal(_canon(out[i, :counts[i]]), _canon(ref))
+
+
+@pytest.mark.parametrize('seed,n,a,ct', [(21, 2, 4000, 0.02), (22, 1, 15000, 1e-5), (23, 3, 9000, 0.3)])
+def test_nms_matches_oracle_order_exact(n6, seed, n, a, ct):
+    from parity_util import random_predictions
+    W, ctx = n6
+    pred = random_predictions(seed, n, a, n_clusters=25)
+    out, counts = ctx.nms_on(pred.numpy(), ct, 0.45, 300)
+    ref = O.nms(pred, conf_thres=ct, iou_thres=0.45, max_det=300)
+    for i in range(n):
+        assert counts[i] == ref[i].shape[0]
+        np.testing.assert_array_equal(out[i, :counts[i]], ref[i].numpy())
+
+
+def test_nms_properties_many_candidates(n6):
+    """sortedness, class-wise non-overlap and idempotence when every anchor is a candidate"""
+    W, ctx = n6
+    a = ctx.num_anchors(320, 320)
+    rng = np.random.default_rng(5)
+    pred = np.zeros((2, a, 8), dtype=np.float32)
+    pred[..., 0:2] = rng.random((2, a, 2)) * 320
+    pred[..., 2:4] = 8 + rng.random((2, a, 2)) * 60
+    pred[..., 4] = rng.random((2, a)) * 0.9 + 0.05
+    pred[..., 5:] = rng.random((2, a, 3))
+    out, counts = ctx.nms_on(pred, 1e-5, 0.45, 300)
+    for i in range(2):
+        k = counts[i]
+        assert 0 < k <= 300
+        d = out[i, :k]
+        assert np.all(np.diff(d[:, 4]) <= 0)
+        for c in range(3):
+            b = d[d[:, 5] == c][:, :4]
+            for p in range(len(b)):
+                for q in range(p + 1, len(b)):
+                    iou = O.get_iou([b[p, 0], b[p, 1], b[p, 2] - b[p, 0], b[p, 3] - b[p, 1]],
+                                    [b[q, 0], b[q, 1], b[q, 2] - b[q, 0], b[q, 3] - b[q, 1]])
+                    assert iou <= 0.45 + 1e-6
+        # idempotence: feeding the survivors back keeps all of them in the same order
+        again = np.zeros((1, k, 8), dtype=np.float32)
+        again[0, :, 0] = (d[:, 0] + d[:, 2]) / 2
+        again[0, :, 1] = (d[:, 1] + d[:, 3]) / 2
+        again[0, :, 2] = d[:, 2] - d[:, 0]
+        again[0, :, 3] = d[:, 3] - d[:, 1]
+        again[0, :, 4] = 1.0
+        again[0, np.arange(k), 5 + d[:, 5].astype(int)] = d[:, 4]
+        out2, c2 = ctx.nms_on(again, 1e-6, 0.46, 300)
+        assert c2[0] == k
+        np.testing.assert_array_equal(out2[0, :k, 5], d[:, 5])
+
+
+# ---------------------------------------------------------------------------------------
+# end to end through the detector seam
+# ---------------------------------------------------------------------------------------
+def test_detector_end_to_end_vs_oracle():
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.detector import HIPDetector
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5N6_TEST, seed=1)
+    det = HIPDetector(W, {'batch_size': 4, 'max_image_size': 320})
+    det.default_image_size = 320
+    det.letterbox_stride = 64
+    imgs = PU.structured_images(3, 240, 320, seed=31) + PU.structured_images(1, 300, 200, seed=32)
+    ids = ['a.jpg', 'b.jpg', 'c.jpg', 'd.jpg']
+    res = det.generate_detections_one_batch(imgs, ids, detection_threshold=1e-5)
+    assert [r['file'] for r in res] == ids
+    assert all('failure' not in r for r in res)
+    # oracle, image by image (batch size forced to 1 on CPU: reference run_detector_batch.py:1219)
+    for im, r in zip(imgs, res):
+        x, infos = PU.oracle_input([im], 320, 64)
+        for emulate, conf_tol, coord_tol in ((True, 0.005, 0.001), (False, 0.005, 0.001)):
+            pred, _ = PU.oracle_forward(W, x, emulate_bf16=emulate)
+            ref = PU.oracle_detections(pred, infos, tuple(x.shape[2:]), 1e-5)[0]
+            hi_a = [d for d in r['detections'] if d['conf'] >= 0.005]
+            hi_b = [d for d in ref['detections'] if d['conf'] >= 0.005]
+            ce, xe = O.compare_detection_lists(hi_a, hi_b)
+            assert ce <= conf_tol + 0.005 and xe <= coord_tol + 2.0 / min(im.shape[:2]), (emulate, ce, xe)
+    # a broken image must not kill the batch (reference pytorch_detector.py:1212-1222)
+    res = det.generate_detections_one_batch([imgs[0], np.zeros((4, 4), np.uint8)], ['ok.jpg', 'bad.jpg'])
+    assert res[1]['failure'] == 'image access failure' and res[1]['detections'] is None
+    assert res[0]['detections'] is not None
+    one = det.generate_detections_one_image(imgs[0], 'ok.jpg', detection_threshold=1e-5)
+    assert one['detections'] == res[0]['detections']

@@ -30,6 +30,8 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, '/root/reference')
 
 from oracle import pre_post as O  # noqa: E402
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+from parity_util import random_predictions  # noqa: E402
 
 
 def _stub(name, **attrs):
@@ -73,19 +75,6 @@ def identical_predictions():
     p[0, 0, :] = torch.tensor([100, 100, 50, 50, 0.9, 0.9, 0.05, 0.05])
     p[0, 1, :] = torch.tensor([100, 100, 50, 50, 0.9, 0.7, 0.1, 0.1])
     return p
-
-
-def random_predictions(seed, batch, n, n_clusters=12, img=1280.0):
-    """Clustered boxes so that suppression actually happens; obj skewed towards 0."""
-    g = torch.Generator().manual_seed(seed)
-    centres = torch.rand(n_clusters, 2, generator=g) * img
-    sizes = 40 + torch.rand(n_clusters, 2, generator=g) * 300
-    which = torch.randint(0, n_clusters, (batch, n), generator=g)
-    xy = centres[which] + torch.randn(batch, n, 2, generator=g) * 12
-    wh = sizes[which] * (1 + 0.15 * torch.randn(batch, n, 2, generator=g)).clamp(0.3, 2)
-    obj = torch.rand(batch, n, 1, generator=g) ** 6
-    cls = torch.rand(batch, n, 3, generator=g)
-    return torch.cat([xy, wh, obj, cls], 2).float()
 
 
 def main():
