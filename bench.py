@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""
+bench.py -- images/s of the MDv5a batch-inference hot path on MI355X.
+
+One "step" = one pass of the whole hot path over one batch of synthetic input that is already
+resident in HBM:  letterbox/normalise (HIP) -> YOLOv5x6 conv stack (HIP, MFMA bf16) -> Detect
+decode (HIP) -> per-image NMS (HIP) -> D2H of <=300 boxes/image -> host formatting to
+MegaDetector detection dicts (the vectorised replacement of reference
+pytorch_detector.py:1361-1422).  Workload = BASELINE.json configs[1]: MDv5a bf16, 1280 px
+letterbox, batch 32 on one MI355X; with --gpus N every rank runs the same per-GPU workload on
+its own GPU (the image queue shards embarrassingly, no collectives: SURVEY.md section 8(e)).
+
+Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+                 --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+GFLOP_PER_IMAGE_1280 = 831.64      # 415.82 GMAC over 163 convs
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--size', type=int, default=1280)
+    ap.add_argument('--model', default='YOLOV5X6_MD')
+    ap.add_argument('--threshold', type=float, default=1e-5,
+                    help='detection threshold handed to NMS (batch mode default of the reference)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=14.0)
+    ap.add_argument('--tuned', default=os.path.join(REPO, 'megadetector_amd', 'tuned_cfgs.json'))
+    ap.add_argument('--profile-out', default=None, help='write per-op timings (json) here')
+    return ap.parse_args()
+
+
+def cpu_baseline(weights, size, threshold, budget_s):
+    """The oracle (CPU restatement of the reference's path) timed on this host's cores."""
+    import torch
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import parity_util as PU
+    from oracle import yolov5 as Y
+    cores = torch.get_num_threads()
+    fw = Y.Forward(weights.yaml, weights.torch_state(), emulate_bf16=False)
+    imgs = PU.random_images(2, size, size, seed=100)
+
+    def one(img):
+        x, infos = PU.oracle_input([img], size, weights.max_stride)
+        with torch.no_grad():
+            pred = fw(x)
+        return PU.oracle_detections(pred, infos, tuple(x.shape[2:]), threshold)
+
+    small = PU.random_images(1, 256, 256, seed=1)[0]
+    one(small)                                   # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one(imgs[n % 2])
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 16:
+            break
+    return {'value': n / el, 'unit': 'images/s', 'cores': int(cores), 'kind': 'port',
+            'sample': '{} synthetic {}x{} images, batch 1 (CPU batch size is forced to 1 by the '
+                      'reference), oracle fp32 torch-CPU forward + NMS + formatting, {:.1f} s'.format(
+                          n, size, size, el)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    from megadetector_amd.postprocess import format_detections
+
+    B, S = args.batch, args.size
+    yaml = getattr(yolo_yaml, args.model)
+    weights = weights_io.synthetic_weights(yaml, seed=0)
+    ctx = HipContext(weights, device=local_rank, dtype='bf16', max_batch=B, max_h=S, max_w=S)
+
+    # measured tile choices (tools/autotune.py), keyed by op name
+    if args.tuned and os.path.exists(args.tuned):
+        tuned = json.load(open(args.tuned)).get('{}:{}:{}'.format(args.model, B, S), {})
+        by_name = {o['name']: o['op'] for o in ctx.op_infos()}
+        for name, cfg in tuned.items():
+            if name in by_name:
+                ctx.set_op_cfg(by_name[name], int(cfg))
+
+    # synthetic uint8 RGB batches, resident in HBM before the timed region
+    n_batches = 4
+    gen = torch.Generator(device='cuda')
+    batches = []
+    for i in range(n_batches):
+        gen.manual_seed(1000 * rank + i)
+        batches.append(torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda', generator=gen))
+    geoms = [(S, S, S, S, 0, 0)] * B
+    ptr_lists = [[int(b[i].data_ptr()) for i in range(B)] for b in batches]
+    torch.cuda.synchronize()
+
+    def step(i):
+        ctx.preprocess(ptr_lists[i % n_batches], geoms, S, S)
+        ctx.forward(B, S, S)
+        det, counts = ctx.nms(B, args.threshold, 0.45, 300)
+        out = []
+        for b in range(B):
+            out.append(format_detections(det[b, :counts[b]], (S, S), (S, S, 3), (S, S, 3), args.threshold))
+        return out, counts
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out, counts = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-stage and per-kernel timing (outside the timed region) --------------------
+    stages = {}
+    roof = None
+    if rank == 0:
+        def timed(fn, reps=3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps * 1e3
+        stages['preprocess_ms'] = timed(lambda: ctx.preprocess(ptr_lists[0], geoms, S, S))
+        stages['forward_ms'] = timed(lambda: ctx.forward(B, S, S))
+        stages['nms_d2h_ms'] = timed(lambda: ctx.nms(B, args.threshold, 0.45, 300))
+        det, cnt = ctx.nms(B, args.threshold, 0.45, 300)
+        t = time.perf_counter()
+        for b in range(B):
+            format_detections(det[b, :cnt[b]], (S, S), (S, S, 3), (S, S, 3), args.threshold)
+        stages['host_format_ms'] = (time.perf_counter() - t) * 1e3
+        stages['mean_detections_per_image'] = float(np.mean(cnt))
+
+        reps = 3
+        ms = np.zeros(ctx.num_ops(), dtype=np.float64)
+        for _ in range(reps):
+            ms += ctx.forward_timed(B, S, S)
+        ms /= reps
+        infos = ctx.op_infos()
+        conv = [(o, ms[o['op']]) for o in infos if o['kind'] == 0]
+        conv_flops = sum(o['flops'] for o, _ in conv)
+        conv_ms = sum(t for _, t in conv)
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                'kernel': 'conv_igemm_kernel (all {} launches of one step)'.format(len(conv)),
+                'flops_per_step': conv_flops, 'kernel_ms_per_step': round(conv_ms, 3),
+                'other_kernels_ms_per_step': round(float(ms.sum() - conv_ms), 3)}
+        if args.model == 'YOLOV5X6_MD' and S == 1280:
+            assert abs(conv_flops / B / 1e9 - GFLOP_PER_IMAGE_1280) < 0.05, conv_flops / B / 1e9
+        if args.profile_out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)), exist_ok=True)
+            with open(args.profile_out, 'w') as f:
+                json.dump([dict(o, ms=float(ms[o['op']]),
+                                tflops=(o['flops'] / (ms[o['op']] * 1e-3) / 1e12 if ms[o['op']] > 0 else 0.0),
+                                gbps=(o['bytes'] / (ms[o['op']] * 1e-3) / 1e9 if ms[o['op']] > 0 else 0.0))
+                           for o in infos], f, indent=1)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(weights, S, args.threshold, args.cpu_seconds)
+
+    if rank == 0:
+        total_images = world * B * args.steps
+        line = {
+            'metric': 'images/sec (whole node) MDv5a @1280px batch inference',
+            'value': round(total_images / elapsed, 2),
+            'unit': 'images/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'bf16',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'MDv5a topology (YOLOv5x6, nc=3, 163 convs, 831.64 GFLOP/image) bf16, '
+                            '{0}x{0} letterbox, batch {1} per GPU, uint8 RGB inputs resident in HBM, seeded '
+                            'synthetic weights (no checkpoint available offline), NMS threshold {2}'.format(S, B, args.threshold),
+                'model': args.model, 'batch_per_gpu': B, 'image_size': S,
+                'parallelism': 'image queue sharded over {} GPU(s), one process per GPU, no collectives'.format(world),
+            },
+            'roofline': roof,
+            'cpu_baseline': cpu,
+            'stages': stages,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

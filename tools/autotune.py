@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""
+Measures every implicit-GEMM tile configuration on every conv op of a model at a given
+(batch, size) on the GPU and records the fastest per op.  Output (json):
+  { "<MODEL>:<batch>:<size>": { "<op name>": cfg, ... } }   -> megadetector_amd/tuned_cfgs.json
+plus a human-readable table (per op: ms and TFLOP/s per configuration).
+
+Run on the GPU box:  python tools/autotune.py --out gpurun_out/tuned_cfgs.json
+"""
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--model', default='YOLOV5X6_MD')
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--size', type=int, default=1280)
+    ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'tuned_cfgs.json'))
+    ap.add_argument('--table', default=None)
+    args = ap.parse_args()
+
+    import torch
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    B, S = args.batch, args.size
+    W = weights_io.synthetic_weights(getattr(yolo_yaml, args.model), seed=0)
+    ctx = HipContext(W, device=0, max_batch=B, max_h=S, max_w=S)
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda')
+    ctx.preprocess([int(x[i].data_ptr()) for i in range(B)], [(S, S, S, S, 0, 0)] * B, S, S)
+    ctx.forward(B, S, S)                       # real activations in every buffer
+    infos = ctx.op_infos()
+    ncfg = ctx.num_conv_cfgs()
+    best = {}
+    lines = []
+    cache = {}
+    for o in infos:
+        if o['kind'] != 0:
+            continue
+        sig = (o['m'], o['n'], o['k'], o['name'].split()[-1], 'res' if '.cv2 3x3' in o['name'] else '')
+        if sig in cache:
+            ms = cache[sig]
+        else:
+            ms = []
+            for cfg in range(ncfg):
+                try:
+                    ctx.set_op_cfg(o['op'], cfg)
+                    ms.append(ctx.time_op(o['op'], B, S, S, iters=args.iters))
+                except Exception:
+                    ms.append(float('inf'))
+            ctx.set_op_cfg(o['op'], -1)
+            cache[sig] = ms
+        b = int(np.argmin(ms))
+        best[o['name']] = b
+        tf = [o['flops'] / (t * 1e-3) / 1e12 if np.isfinite(t) else 0.0 for t in ms]
+        lines.append('{:34s} M={:8d} N={:5d} K={:6d} default={:2d} best={:2d} {:8.3f} ms {:7.1f} TF/s | '.format(
+            o['name'], o['m'], o['n'], o['k'], o['cfg'], b, ms[b], tf[b]) +
+            ' '.join('{:6.1f}'.format(t) for t in tf))
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    key = '{}:{}:{}'.format(args.model, B, S)
+    data = {}
+    if os.path.exists(args.out):
+        try:
+            data = json.load(open(args.out))
+        except Exception:
+            data = {}
+    data[key] = best
+    json.dump(data, open(args.out, 'w'), indent=1, sort_keys=True)
+    table = args.table or (os.path.splitext(args.out)[0] + '_{}_{}_{}.txt'.format(args.model, B, S))
+    with open(table, 'w') as f:
+        f.write('TFLOP/s per configuration (columns = cfg 0..{})\n'.format(ncfg - 1))
+        f.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()
