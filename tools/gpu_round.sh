@@ -10,7 +10,7 @@ echo "== rocminfo ==" > gpurun_out/env.log
 (rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; nproc; free -g | head -2) >> gpurun_out/env.log 2>&1
 
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "test" ]; then
-  timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pytest_gpu.log 2>&1
+  timeout 900 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
   timeout 300 python tools/gpu_diag.py YOLOV5N6_TEST 256 2 > gpurun_out/diag_n6.log 2>&1
 fi
