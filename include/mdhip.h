@@ -102,7 +102,7 @@ const char* mdhip_last_error(mdhip_ctx* ctx);
 
 /* Replaces letterbox() + HWC->CHW + float() + /255 (pytorch_detector.py:1104-1109,
  * :1283-1310).  images[i]: HWC uint8 RGB, src_h x src_w, host or device memory
- * (host memory is staged through a pinned ring).  Output: the context's network input,
+ * (host images are copied to a device staging area first).  Output: the context's network input,
  * n x out_h x out_w.  out_h/out_w must be multiples of the model's largest stride. */
 int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_letterbox* geom,
                      int n, int out_h, int out_w, void* hip_stream);
@@ -117,6 +117,17 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream);
  * results are in host memory. */
 int mdhip_nms(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_det,
               float* out, int32_t* counts, void* hip_stream);
+
+/* Asynchronous form of mdhip_nms, for overlapping the host-side formatting of batch i
+ * (pytorch_detector.py:1361-1422) with the GPU work of batch i+1: the kernel and the D2H copies
+ * are enqueued on the stream and the call returns; results land in pinned host slot `slot`
+ * (0 <= slot < MDHIP_NMS_SLOTS) owned by the context.  mdhip_nms_wait blocks until that slot is
+ * complete and returns pointers into it ([n][max_det][6] floats, [n] counts), valid until the
+ * slot is enqueued again. */
+#define MDHIP_NMS_SLOTS 4
+int mdhip_nms_enqueue(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_det,
+                      int slot, void* hip_stream);
+int mdhip_nms_wait(mdhip_ctx* ctx, int slot, const float** out, const int32_t** counts);
 
 /* nms() on caller-supplied predictions (host, [n][n_anchors][5+nc] fp32); any n_anchors up to
  * the context's capacity.  Used by the parity tests against the reference's NMS vectors. */

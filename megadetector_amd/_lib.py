@@ -56,6 +56,8 @@ SYMBOLS = {
     'mdhip_preprocess': (C.c_int, [_P, C.POINTER(_P), C.POINTER(mdhip_letterbox), C.c_int, C.c_int, C.c_int, _P]),
     'mdhip_forward': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     'mdhip_nms': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
+    'mdhip_nms_enqueue': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _P]),
+    'mdhip_nms_wait': (C.c_int, [_P, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_int32))]),
     'mdhip_nms_on': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
     'mdhip_num_anchors': (C.c_int, [_P, C.c_int, C.c_int]),
     'mdhip_max_stride': (C.c_int, [_P]),

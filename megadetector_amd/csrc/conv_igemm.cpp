@@ -16,7 +16,11 @@
 //   LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row & 7) on the source
 //   side and on the ds_read_b128 side (guide rule 21: linear LDS destination, same involution
 //   on source and read) so that fragment reads are bank-conflict free.
-//   Two LDS stages: the loads of slab k+1 are in flight while slab k feeds the MFMAs.
+//   NS LDS stages form a ring: the loads of slabs k+1 .. k+NS-1 are in flight while slab k feeds
+//   the MFMAs.  A wave waits for its own slab-k loads with a *counted* s_waitcnt vmcnt(N)
+//   (younger slabs stay in flight), then one raw s_barrier per slab makes every wave's part
+//   of slab k visible and releases the stage that was consumed in the previous iteration
+//   (guide: glds across barriers needs raw s_barrier + counted vmcnt, never __syncthreads()).
 //
 // MFMA: v_mfma_f32_16x16x32_bf16 with the operands swapped (weights as "A", pixels as "B") so
 //   that each lane ends up with 4 *consecutive output channels* of one pixel: the epilogue is
@@ -45,7 +49,12 @@ __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
     return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_igemm_kernel(const ConvArgs p) {
     constexpr int NW = WM * WN;
@@ -57,6 +66,7 @@ conv_igemm_kernel(const ConvArgs p) {
     constexpr int A_PER = A_INSTR / NW;
     constexpr int B_PER = (B_INSTR + NW - 1) / NW;
     static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
+    static_assert(NS >= 2 && (NS - 2) * (A_PER + B_PER) < 64, "vmcnt is a 6-bit counter");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -168,14 +178,26 @@ conv_igemm_kernel(const ConvArgs p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.k_pad >> 6;
+    // number of weight-tile load instructions this wave issues per slab (wave-uniform)
+    const bool b_full = ((B_PER - 1) * NW + wave) < B_INSTR;
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // prologue: slabs 0 .. NS-2 in flight
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < KT) stage(st, st);
 
+    int cur = 0;                 // ring slot of slab kt
+    int nxt = NS - 1;            // ring slot the next issued slab goes to
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+        // own loads of slab kt have landed; up to NS-2 younger slabs may stay in flight
+        if (kt + (NS - 2) < KT) {
+            if (b_full) wait_vmcnt<(NS - 2) * (A_PER + B_PER)>();
+            else wait_vmcnt<(NS - 2) * (A_PER + B_PER - 1)>();
+        } else {
+            wait_vmcnt<0>();     // tail: fewer slabs are outstanding than the steady-state count
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < KT) stage(kt + NS - 1, nxt);
 
         const char* sbase = smem + cur * STAGE;
 #pragma unroll
@@ -194,8 +216,8 @@ conv_igemm_kernel(const ConvArgs p) {
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
 
     // ---- epilogue: lane holds channels n..n+3 of pixel m --------------------------------
@@ -237,22 +259,35 @@ conv_igemm_kernel(const ConvArgs p) {
 // ---------------------------------------------------------------------------------------
 // configuration table
 // ---------------------------------------------------------------------------------------
-#define MDHIP_CONV_CFGS(X) \
-    X(0, 256, 160, 4, 2)   \
-    X(1, 128, 160, 2, 2)   \
-    X(2, 256, 80, 4, 1)    \
-    X(3, 128, 80, 4, 1)    \
-    X(4, 256, 32, 4, 1)    \
-    X(5, 128, 64, 2, 2)    \
-    X(6, 128, 128, 2, 2)   \
-    X(7, 256, 128, 4, 2)   \
-    X(8, 128, 320, 2, 4)   \
-    X(9, 64, 160, 1, 2)    \
-    X(10, 64, 64, 1, 2)    \
-    X(11, 256, 64, 4, 1)
+// id, BM, BN, waves along M, waves along N, LDS stages
+#define MDHIP_CONV_CFGS(X)  \
+    X(0, 256, 160, 4, 2, 2) \
+    X(1, 128, 160, 2, 2, 2) \
+    X(2, 256, 80, 4, 1, 2)  \
+    X(3, 128, 80, 4, 1, 2)  \
+    X(4, 256, 32, 4, 1, 2)  \
+    X(5, 128, 64, 2, 2, 2)  \
+    X(6, 128, 128, 2, 2, 2) \
+    X(7, 256, 128, 4, 2, 2) \
+    X(8, 128, 320, 2, 4, 2) \
+    X(9, 64, 160, 1, 2, 2)  \
+    X(10, 64, 64, 1, 2, 2)  \
+    X(11, 256, 64, 4, 1, 2) \
+    X(12, 256, 160, 4, 2, 3) \
+    X(13, 128, 160, 2, 2, 3) \
+    X(14, 128, 160, 2, 2, 4) \
+    X(15, 128, 80, 4, 1, 3)  \
+    X(16, 128, 80, 4, 1, 4)  \
+    X(17, 256, 80, 4, 1, 3)  \
+    X(18, 256, 128, 4, 2, 3) \
+    X(19, 128, 128, 2, 2, 3) \
+    X(20, 128, 128, 2, 2, 4) \
+    X(21, 64, 160, 1, 2, 4)  \
+    X(22, 128, 64, 2, 2, 4)  \
+    X(23, 256, 32, 4, 1, 4)
 
 static const ConvCfg g_cfgs[] = {
-#define X(id, bm, bn, wm, wn) {bm, bn, (wm) * (wn) * 64, (size_t)2 * ((bm) + (bn)) * 128, #bm "x" #bn "/" #wm "x" #wn},
+#define X(id, bm, bn, wm, wn, ns) {bm, bn, (wm) * (wn) * 64, (size_t)(ns) * ((bm) + (bn)) * 128, #bm "x" #bn "/" #wm "x" #wn "/s" #ns},
     MDHIP_CONV_CFGS(X)
 #undef X
 };
@@ -262,9 +297,9 @@ const ConvCfg& conv_cfg(int i) { return g_cfgs[i]; }
 
 hipError_t conv_init() {
     hipError_t e = hipSuccess;
-#define X(id, bm, bn, wm, wn)                                                                      \
+#define X(id, bm, bn, wm, wn, ns)                                                                  \
     if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<bm, bn, wm, wn>,                    \
+        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<bm, bn, wm, wn, ns>,                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs[id].lds_bytes);
     MDHIP_CONV_CFGS(X)
 #undef X
@@ -279,9 +314,9 @@ hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + c.bm - 1) / c.bm;
     const dim3 grid((unsigned)(tiles_m * p.tiles_n));
     switch (cfg) {
-#define X(id, bm, bn, wm, wn)                                                                     \
+#define X(id, bm, bn, wm, wn, ns)                                                                 \
     case id:                                                                                      \
-        hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn>), grid, dim3((wm) * (wn) * 64),     \
+        hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, ns>), grid, dim3((wm) * (wn) * 64), \
                            c.lds_bytes, s, p);                                                    \
         break;
         MDHIP_CONV_CFGS(X)

@@ -98,6 +98,14 @@ struct mdhip_ctx {
     int last_n = 0, last_h = 0, last_w = 0;
     std::string err;
     std::vector<hipEvent_t> events;
+    // pinned host staging: letterbox geometry ring + asynchronous NMS result slots
+    LetterboxDev* geom_host = nullptr;
+    int geom_slot = 0;
+    hipEvent_t geom_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* nms_host_out[MDHIP_NMS_SLOTS] = {};
+    int32_t* nms_host_cnt[MDHIP_NMS_SLOTS] = {};
+    hipEvent_t nms_ev[MDHIP_NMS_SLOTS] = {};
+    int nms_slot_n[MDHIP_NMS_SLOTS] = {};
 };
 
 namespace {
@@ -488,7 +496,10 @@ int check_shape(mdhip_ctx* ctx, int n, int h, int w) {
 
 // heuristic tile choice; measured overrides arrive through mdhip_set_op_cfg
 int choose_cfg(int M, int n_rows) {
-    static const float quality[] = {1.00f, 0.90f, 0.85f, 0.70f, 0.45f, 0.60f, 0.85f, 0.95f, 1.00f, 0.60f, 0.40f, 0.65f};
+    // prior from measurements on MI355X (profiles/autotune_r1.txt); tools/autotune.py refines it
+    static const float quality[] = {0.92f, 1.00f, 0.55f, 0.95f, 0.45f, 0.70f, 0.85f, 0.85f, 0.95f, 0.55f, 0.45f, 0.65f,
+                                    0.95f, 1.00f, 1.00f, 0.95f, 0.95f, 0.60f, 0.90f, 0.88f, 0.88f, 0.55f, 0.70f, 0.45f};
+    static_assert(sizeof(quality) / sizeof(quality[0]) == 24, "one prior per tile configuration");
     int best = 0;
     float best_score = -1.f;
     for (int i = 0; i < conv_num_cfgs(); ++i) {
@@ -705,6 +716,13 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     CREATE_TRY(hipMalloc((void**)&ctx->arena, ctx->arena_bytes));
     CREATE_TRY(hipMalloc((void**)&ctx->warena, ctx->warena_bytes));
     CREATE_TRY(hipMemset(ctx->warena, 0, 256));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->geom_host, (size_t)4 * max_batch * sizeof(LetterboxDev), hipHostMallocDefault));
+    for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreateWithFlags(&ctx->geom_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < MDHIP_NMS_SLOTS; ++i) {
+        CREATE_TRY(hipHostMalloc((void**)&ctx->nms_host_out[i], (size_t)max_batch * kNmsMaxDet * 6 * 4, hipHostMallocDefault));
+        CREATE_TRY(hipHostMalloc((void**)&ctx->nms_host_cnt[i], (size_t)max_batch * 4, hipHostMallocDefault));
+        CREATE_TRY(hipEventCreateWithFlags(&ctx->nms_ev[i], hipEventDisableTiming));
+    }
     CREATE_TRY(hipMemset(ctx->arena, 0, std::min(ctx->arena_bytes, (size_t)1 << 20)));
     if (has_detect)
         CREATE_TRY(hipMemcpy(ctx->warena + ctx->anchors_off, model->anchors_px, (size_t)ctx->nl * ctx->na * 2 * 4, hipMemcpyHostToDevice));
@@ -730,6 +748,13 @@ void mdhip_destroy(mdhip_ctx* ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->warena) (void)hipFree(ctx->warena);
     if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->geom_host) (void)hipHostFree(ctx->geom_host);
+    for (int i = 0; i < 4; ++i) if (ctx->geom_ev[i]) (void)hipEventDestroy(ctx->geom_ev[i]);
+    for (int i = 0; i < MDHIP_NMS_SLOTS; ++i) {
+        if (ctx->nms_host_out[i]) (void)hipHostFree(ctx->nms_host_out[i]);
+        if (ctx->nms_host_cnt[i]) (void)hipHostFree(ctx->nms_host_cnt[i]);
+        if (ctx->nms_ev[i]) (void)hipEventDestroy(ctx->nms_ev[i]);
+    }
     delete ctx;
 }
 
@@ -780,10 +805,14 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
         g[i].src = (const uint8_t*)(ctx->stage + cur);
         cur += align_up(bytes, 256);
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena + ctx->geom_off, g.data(), n * sizeof(LetterboxDev), hipMemcpyHostToDevice, s));
-    // g is a stack-owned pageable buffer: the async copy above is staged synchronously by the runtime,
-    // but make that explicit so the vector may die safely.
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    // geometry goes through a 4-deep pinned ring so that the call never blocks on the stream
+    const int slot = ctx->geom_slot;
+    ctx->geom_slot = (slot + 1) & 3;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->geom_ev[slot]));          // slot's previous copy has completed
+    LetterboxDev* gh = ctx->geom_host + (size_t)slot * ctx->max_batch;
+    memcpy(gh, g.data(), n * sizeof(LetterboxDev));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena + ctx->geom_off, gh, n * sizeof(LetterboxDev), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->geom_ev[slot], s));
     HIP_TRY(ctx, launch_letterbox_s2d((const LetterboxDev*)(ctx->arena + ctx->geom_off), n, out_h, out_w,
                                       (uint16_t*)(ctx->arena + ctx->input.off), s));
     ctx->last_n = n;
@@ -875,6 +904,37 @@ int mdhip_nms(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_
     const int A = num_anchors_for(ctx, ctx->last_h, ctx->last_w);
     return nms_common(ctx, (const float*)(ctx->arena + ctx->pred_off), n, A, conf_thres, iou_thres,
                       max_det, out, counts, (hipStream_t)hip_stream);
+}
+
+int mdhip_nms_enqueue(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_det, int slot,
+                      void* hip_stream) {
+    if (!ctx) return MDHIP_EINVAL;
+    if (ctx->last_h == 0) return fail(ctx, MDHIP_EINVAL, "mdhip_nms_enqueue before mdhip_forward");
+    if (slot < 0 || slot >= MDHIP_NMS_SLOTS) return fail(ctx, MDHIP_EINVAL, "slot %d outside [0,%d)", slot, MDHIP_NMS_SLOTS);
+    if (n < 1 || n > ctx->max_batch) return fail(ctx, MDHIP_EINVAL, "batch %d outside [1,%d]", n, ctx->max_batch);
+    if (max_det < 1 || max_det > kNmsMaxDet) return fail(ctx, MDHIP_EINVAL, "max_det %d outside [1,%d]", max_det, kNmsMaxDet);
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int A = num_anchors_for(ctx, ctx->last_h, ctx->last_w);
+    float* out_dev = (float*)(ctx->arena + ctx->nms_out_off);
+    int* cnt_dev = (int*)(ctx->arena + ctx->nms_cnt_off);
+    HIP_TRY(ctx, launch_nms((const float*)(ctx->arena + ctx->pred_off), n, A, ctx->no, conf_thres, iou_thres, max_det,
+                            ctx->nms_scr, out_dev, cnt_dev, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nms_host_out[slot], out_dev, (size_t)n * max_det * 6 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nms_host_cnt[slot], cnt_dev, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->nms_ev[slot], s));
+    ctx->nms_slot_n[slot] = n;
+    return MDHIP_OK;
+}
+
+int mdhip_nms_wait(mdhip_ctx* ctx, int slot, const float** out, const int32_t** counts) {
+    if (!ctx || !out || !counts) return MDHIP_EINVAL;
+    if (slot < 0 || slot >= MDHIP_NMS_SLOTS || ctx->nms_slot_n[slot] == 0)
+        return fail(ctx, MDHIP_EINVAL, "nothing enqueued in slot %d", slot);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->nms_ev[slot]));
+    *out = ctx->nms_host_out[slot];
+    *counts = ctx->nms_host_cnt[slot];
+    return MDHIP_OK;
 }
 
 int mdhip_nms_on(mdhip_ctx* ctx, const float* pred, int n, int n_anchors, float conf_thres,

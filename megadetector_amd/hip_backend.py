@@ -120,6 +120,23 @@ class HipContext:
                                        _lib.np_ptr(out), _lib.np_ptr(counts), C.c_void_p(stream)), 'mdhip_nms')
         return out, counts
 
+    def nms_enqueue(self, n, conf_thres, iou_thres, max_det=300, slot=0, stream=0):
+        """asynchronous NMS + D2H into pinned slot `slot`; pair with nms_wait(slot)"""
+        self._check(self.lib.mdhip_nms_enqueue(self.h, int(n), float(conf_thres), float(iou_thres), int(max_det),
+                                               int(slot), C.c_void_p(stream)), 'mdhip_nms_enqueue')
+        self._slot_shape = getattr(self, '_slot_shape', {})
+        self._slot_shape[slot] = (int(n), int(max_det))
+
+    def nms_wait(self, slot=0):
+        """blocks until slot is complete; returns numpy *views* of the pinned slot (valid until re-enqueued)"""
+        out = C.POINTER(C.c_float)()
+        cnt = C.POINTER(C.c_int32)()
+        self._check(self.lib.mdhip_nms_wait(self.h, int(slot), C.byref(out), C.byref(cnt)), 'mdhip_nms_wait')
+        n, max_det = self._slot_shape[slot]
+        det = np.ctypeslib.as_array(out, shape=(n, max_det, 6))
+        counts = np.ctypeslib.as_array(cnt, shape=(n,))
+        return det, counts
+
     def nms_on(self, pred, conf_thres, iou_thres, max_det=300, stream=0):
         pred = np.ascontiguousarray(pred, dtype=np.float32)
         n, a, no = pred.shape
