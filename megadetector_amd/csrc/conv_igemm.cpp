@@ -11,8 +11,10 @@
 //   (r, s, c) so that every 16-byte chunk (8 channels) of an A row is contiguous in HBM.
 //
 // Data movement (per workgroup, per 64-wide K slab):
-//   HBM/L2 --global_load_lds 16B/lane--> LDS  (no VGPR round trip; the per-lane *source*
-//   address does the im2col gather, zero padding reads a 16-byte zero page)
+//   HBM/L2 --buffer_load_dwordx4 ... lds, 16 B/lane--> LDS  (no VGPR round trip; the per-lane
+//   *source* offset does the im2col gather; conv padding, K padding and ragged tiles are lanes
+//   whose offset is out of the descriptor's range, which the hardware returns as zeros; the
+//   K-slab advance of the weight tile is a wave-uniform SGPR offset: no per-lane arithmetic)
 //   LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row & 7) on the source
 //   side and on the ds_read_b128 side (guide rule 21: linear LDS destination, same involution
 //   on source and read) so that fragment reads are bank-conflict free.
@@ -36,10 +38,16 @@ namespace mdhip {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#define MDHIP_GLDS16(gptr, lptr)                                                        \
-    __builtin_amdgcn_global_load_lds(                                                   \
-        (const __attribute__((address_space(1))) void*)(gptr),                          \
-        (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+typedef __attribute__((address_space(3))) char lds_char;
+
+// 16 bytes per lane, HBM/L2 -> LDS directly: LDS address = m0-base (wave-uniform) + lane*16;
+// source = descriptor base + voff (per lane) + soff (wave-uniform SGPR).  A lane whose voff is
+// >= num_records reads zeros: that is how conv padding, K padding and ragged tiles are done.
+#define MDHIP_BLDS16(rsrc, lptr, voff, soff) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr), 16, (voff), (soff), 0, 0)
+
+constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records
+constexpr int kNumRecords = 0x7fffffff;
 
 __device__ __forceinline__ float silu_f32(float x) {
     return x / (1.0f + __expf(-x));
@@ -69,7 +77,12 @@ conv_igemm_kernel(const ConvArgs p) {
     static_assert(NS >= 2 && (NS - 2) * (A_PER + B_PER) < 64, "vmcnt is a 6-bit counter");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int B_SLOTS = B_PER * NW;             // B load instructions incl. overflow slots
+    static_assert(STAGE == A_BYTES + B_BYTES, "");
+    constexpr int STAGE_LDS = A_BYTES + B_SLOTS * 1024;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lds_char* const smem = (lds_char*)smem_generic;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -88,19 +101,35 @@ conv_igemm_kernel(const ConvArgs p) {
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+    // ---- buffer descriptors (wave-uniform, built from scalars only) ---------------------
+    // A: based at the tile's first pixel minus the conv padding, so every in-range tap of
+    // every row of the tile has a small non-negative byte offset.
+    long long base_px;
+    {
+        const int b0 = m0 / p.HoWo;
+        const int rem0 = m0 - b0 * p.HoWo;
+        const int oy0 = rem0 / p.Wo;
+        const int ox0 = rem0 - oy0 * p.Wo;
+        base_px = (long long)(b0 * p.H + oy0 * p.stride - p.pad) * p.W + (ox0 * p.stride - p.pad);
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.in + base_px * p.ld_in), 0, kNumRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.wgt + (size_t)n0 * p.k_pad), 0, kNumRecords, 0x00020000);
+
     // ---- loader geometry ---------------------------------------------------------------
     const int lr = lane >> 3;              // row inside an 8-row load instruction (== row & 7)
     const int jj = (lane & 7) ^ lr;        // swizzled source chunk inside the 128-byte K slab
 
-    const uint16_t* a_ptr[A_PER];
-    uint32_t a_mask[A_PER];
+    unsigned a_off[A_PER];                 // byte offset of the row's (tap 0, channel 0) from the A base
+    uint32_t a_mask[A_PER];                // bit t set: tap t of this row is inside the image
     const int kh = p.ntaps / p.kw;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         const int row = (i * NW + wave) * 8 + lr;
         const int m = m0 + row;
         uint32_t mask = 0;
-        const uint16_t* ptr = p.in;
+        unsigned off = 0;
         if (m < p.M) {
             const int b = m / p.HoWo;
             const int rem = m - b * p.HoWo;
@@ -108,7 +137,8 @@ conv_igemm_kernel(const ConvArgs p) {
             const int ox = rem - oy * p.Wo;
             const int iy0 = oy * p.stride - p.pad;
             const int ix0 = ox * p.stride - p.pad;
-            ptr = p.in + ((long long)(b * p.H + iy0) * p.W + ix0) * p.ld_in;
+            const long long px = (long long)(b * p.H + iy0) * p.W + ix0;
+            off = (unsigned)((px - base_px) * p.ld_in * 2);
 #pragma unroll
             for (int r = 0; r < 3; ++r)          // kernels are 1x1 or 3x3 (planner enforces it)
 #pragma unroll
@@ -117,14 +147,14 @@ conv_igemm_kernel(const ConvArgs p) {
                         (unsigned)(ix0 + s) < (unsigned)p.W)
                         mask |= 1u << (r * p.kw + s);
         }
-        a_ptr[i] = ptr;
+        a_off[i] = off;
         a_mask[i] = mask;
     }
-    const uint16_t* b_ptr[B_PER];
+    unsigned b_off[B_PER];                 // byte offset of (row, chunk jj) from the B base; soffset adds kt*128
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-        const int n = n0 + (i * NW + wave) * 8 + lr;
-        b_ptr[i] = (n < p.n_rows) ? p.wgt + (size_t)n * p.k_pad + jj * 8 : nullptr;
+        const int row = (i * NW + wave) * 8 + lr;
+        b_off[i] = (row < BN && n0 + row < p.n_rows) ? (unsigned)(row * p.k_pad + jj * 8) * 2u : kOOB;
     }
 
     // per-lane position inside K: chunk c8 of tap (tr, ts)
@@ -136,24 +166,19 @@ conv_igemm_kernel(const ConvArgs p) {
     }
 
     auto stage = [&](int kt, int buf) {
-        char* sA = smem + buf * STAGE;
-        char* sB = sA + A_BYTES;
-        const bool tap_ok = tap < p.ntaps;
-        const int tapoff = (tr * p.W + ts) * p.ld_in + c8 * 8;
-        const uint32_t bit = tap_ok ? (1u << (tap & 31)) : 0u;
+        lds_char* sA = smem + buf * STAGE_LDS;
+        lds_char* sB = sA + A_BYTES;
+        const unsigned tapoff = (unsigned)((tr * p.W + ts) * p.ld_in + c8 * 8) * 2u;
+        const uint32_t bit = (tap < p.ntaps) ? (1u << (tap & 31)) : 0u;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const uint16_t* src = (a_mask[i] & bit) ? a_ptr[i] + tapoff : p.zero;
-            MDHIP_GLDS16(src, sA + (i * NW + wave) * 1024);
+            const unsigned voff = (a_mask[i] & bit) ? a_off[i] + tapoff : kOOB;
+            MDHIP_BLDS16(a_rsrc, sA + (i * NW + wave) * 1024, voff, 0);
         }
+        const int soff = kt * 128;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int instr = i * NW + wave;
-            if (instr < B_INSTR) {
-                const uint16_t* src = b_ptr[i] ? b_ptr[i] + kt * 64 : p.zero;
-                MDHIP_GLDS16(src, sB + instr * 1024);
-            }
-        }
+        for (int i = 0; i < B_PER; ++i)
+            MDHIP_BLDS16(b_rsrc, sB + (i * NW + wave) * 1024, b_off[i], soff);
         // advance this lane's K position by one slab (8 chunks)
         c8 += 8;
         while (c8 >= p.C8) {
@@ -178,9 +203,6 @@ conv_igemm_kernel(const ConvArgs p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.k_pad >> 6;
-    // number of weight-tile load instructions this wave issues per slab (wave-uniform)
-    const bool b_full = ((B_PER - 1) * NW + wave) < B_INSTR;
-
     // prologue: slabs 0 .. NS-2 in flight
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
@@ -191,25 +213,24 @@ conv_igemm_kernel(const ConvArgs p) {
     for (int kt = 0; kt < KT; ++kt) {
         // own loads of slab kt have landed; up to NS-2 younger slabs may stay in flight
         if (kt + (NS - 2) < KT) {
-            if (b_full) wait_vmcnt<(NS - 2) * (A_PER + B_PER)>();
-            else wait_vmcnt<(NS - 2) * (A_PER + B_PER - 1)>();
+            wait_vmcnt<(NS - 2) * (A_PER + B_PER)>();
         } else {
             wait_vmcnt<0>();     // tail: fewer slabs are outstanding than the steady-state count
         }
         __builtin_amdgcn_s_barrier();
         if (kt + NS - 1 < KT) stage(kt + NS - 1, nxt);
 
-        const char* sbase = smem + cur * STAGE;
+        const lds_char* sbase = smem + cur * STAGE_LDS;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int choff = frag_ch0 ^ (kk * 64);
             bf16x8 xf[FM], wf[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                xf[i] = *(const bf16x8*)(sbase + a_frag_base + i * 2048 + choff);
+                xf[i] = *(const __attribute__((address_space(3))) bf16x8*)(sbase + a_frag_base + i * 2048 + choff);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                wf[j] = *(const bf16x8*)(sbase + b_frag_base + j * 2048 + choff);
+                wf[j] = *(const __attribute__((address_space(3))) bf16x8*)(sbase + b_frag_base + j * 2048 + choff);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -287,7 +308,10 @@ conv_igemm_kernel(const ConvArgs p) {
     X(23, 256, 32, 4, 1, 4)
 
 static const ConvCfg g_cfgs[] = {
-#define X(id, bm, bn, wm, wn, ns) {bm, bn, (wm) * (wn) * 64, (size_t)(ns) * ((bm) + (bn)) * 128, #bm "x" #bn "/" #wm "x" #wn "/s" #ns},
+#define X(id, bm, bn, wm, wn, ns)                                                                   \
+    {bm, bn, (wm) * (wn) * 64,                                                                      \
+     (size_t)(ns) * ((bm) * 128 + (((bn) / 8 + (wm) * (wn) - 1) / ((wm) * (wn))) * (wm) * (wn) * 1024), \
+     #bm "x" #bn "/" #wm "x" #wn "/s" #ns},
     MDHIP_CONV_CFGS(X)
 #undef X
 };

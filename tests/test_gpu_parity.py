@@ -248,7 +248,7 @@ def test_detector_end_to_end_vs_oracle():
             pred, _ = PU.oracle_forward(W, x, emulate_bf16=emulate)
             e_box = PU.rel_err(pred_hip[..., :4].numpy(), pred[..., :4].numpy())
             e_conf = float(np.abs(pred_hip[..., 4:].numpy() - pred[..., 4:].numpy()).max())
-            assert e_box[0] < 5e-2 and e_box[1] < 1e-2 and e_conf < 3e-2, (emulate, e_box, e_conf)
+            assert e_box[0] < 5e-2 and e_box[1] < 1e-2 and e_conf < 6e-2, (emulate, e_box, e_conf)
             ref = PU.oracle_detections(pred, infos, (h, w), thr)[0]
             # the reference's pass bar (md_tests.py:96-100,418-531) on confident detections;
             # greedy NMS is discontinuous at near-ties, so require it for >= 90 % of them
