@@ -65,6 +65,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int BM, int BN, int WM, int WN, int NS>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_igemm_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource
+                                      // type and builtins below do not exist for the x86 target)
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
@@ -275,6 +277,7 @@ conv_igemm_kernel(const ConvArgs p) {
             }
         }
     }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // ---------------------------------------------------------------------------------------
