@@ -79,9 +79,11 @@ conv_igemm_kernel(const ConvArgs p) {
     static_assert(NS >= 2 && (NS - 2) * (A_PER + B_PER) < 64, "vmcnt is a 6-bit counter");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
 
-    constexpr int B_SLOTS = B_PER * NW;             // B load instructions incl. overflow slots
-    static_assert(STAGE == A_BYTES + B_BYTES, "");
-    constexpr int STAGE_LDS = A_BYTES + B_SLOTS * 1024;
+    // every wave issues exactly A_PER + B_PER loads per slab (uniform vmcnt bookkeeping); when
+    // BN/8 does not divide by the wave count the surplus loads are out-of-range (zeros) and land
+    // in one shared 1 KiB dump area behind the last stage
+    constexpr int STAGE_LDS = STAGE;
+    constexpr int DUMP_OFF = NS * STAGE;
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lds_char* const smem = (lds_char*)smem_generic;
@@ -179,8 +181,11 @@ conv_igemm_kernel(const ConvArgs p) {
         }
         const int soff = kt * 128;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i)
-            MDHIP_BLDS16(b_rsrc, sB + (i * NW + wave) * 1024, b_off[i], soff);
+        for (int i = 0; i < B_PER; ++i) {
+            const int instr = i * NW + wave;
+            lds_char* dst = (instr < B_INSTR) ? sB + instr * 1024 : smem + DUMP_OFF;
+            MDHIP_BLDS16(b_rsrc, dst, b_off[i], soff);
+        }
         // advance this lane's K position by one slab (8 chunks)
         c8 += 8;
         while (c8 >= p.C8) {
@@ -313,7 +318,7 @@ conv_igemm_kernel(const ConvArgs p) {
 static const ConvCfg g_cfgs[] = {
 #define X(id, bm, bn, wm, wn, ns)                                                                   \
     {bm, bn, (wm) * (wn) * 64,                                                                      \
-     (size_t)(ns) * ((bm) * 128 + (((bn) / 8 + (wm) * (wn) - 1) / ((wm) * (wn))) * (wm) * (wn) * 1024), \
+     (size_t)(ns) * ((bm) + (bn)) * 128 + 1024,                                                     \
      #bm "x" #bn "/" #wm "x" #wn "/s" #ns},
     MDHIP_CONV_CFGS(X)
 #undef X
