@@ -313,7 +313,11 @@ conv_igemm_kernel(const ConvArgs p) {
     X(20, 128, 128, 2, 2, 4) \
     X(21, 64, 160, 1, 2, 4)  \
     X(22, 128, 64, 2, 2, 4)  \
-    X(23, 256, 32, 4, 1, 4)
+    X(23, 256, 32, 4, 1, 4)  \
+    X(24, 256, 320, 2, 4, 2) \
+    X(25, 256, 160, 2, 2, 2) \
+    X(26, 256, 320, 4, 4, 2) \
+    X(27, 256, 160, 2, 2, 3)
 
 static const ConvCfg g_cfgs[] = {
 #define X(id, bm, bn, wm, wn, ns)                                                                   \

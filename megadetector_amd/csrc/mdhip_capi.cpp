@@ -498,8 +498,9 @@ int check_shape(mdhip_ctx* ctx, int n, int h, int w) {
 int choose_cfg(int M, int n_rows) {
     // prior from measurements on MI355X (profiles/autotune_r1.txt); tools/autotune.py refines it
     static const float quality[] = {0.92f, 1.00f, 0.55f, 0.95f, 0.45f, 0.70f, 0.85f, 0.85f, 0.95f, 0.55f, 0.45f, 0.65f,
-                                    0.95f, 1.00f, 1.00f, 0.95f, 0.95f, 0.60f, 0.90f, 0.88f, 0.88f, 0.55f, 0.70f, 0.45f};
-    static_assert(sizeof(quality) / sizeof(quality[0]) == 24, "one prior per tile configuration");
+                                    0.95f, 1.00f, 1.00f, 0.95f, 0.95f, 0.60f, 0.90f, 0.88f, 0.88f, 0.55f, 0.70f, 0.45f,
+                                    0.50f, 0.50f, 0.50f, 0.50f};
+    static_assert(sizeof(quality) / sizeof(quality[0]) == 28, "one prior per tile configuration");
     int best = 0;
     float best_score = -1.f;
     for (int i = 0; i < conv_num_cfgs(); ++i) {
