@@ -31,6 +31,8 @@
 // Workgroup -> tile mapping is XCD-aware: consecutive tiles (which share im2col halo rows
 //   and the weight panel) are placed on the same XCD/L2.
 
+#include <algorithm>
+
 #include "mdhip_internal.h"
 
 namespace mdhip {
@@ -62,8 +64,21 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// LDS bytes of one workgroup and the residency (workgroups per CU, waves per SIMD) it is built for
+constexpr int conv_lds_bytes(int bm, int bn, int ns) { return ns * (bm + bn) * 128 + 1024 + bn * 4; }
+constexpr int conv_blocks_per_cu(int bm, int bn, int nw, int ns) {
+    int b = 163840 / conv_lds_bytes(bm, bn, ns);
+    if (b > 32 / nw) b = 32 / nw;
+    if (b > 4) b = 4;
+    return b < 1 ? 1 : b;
+}
+constexpr int conv_waves_per_simd(int bm, int bn, int nw, int ns) {
+    int w = conv_blocks_per_cu(bm, bn, nw, ns) * nw / 4;
+    return w < 1 ? 1 : w;
+}
+
 template <int BM, int BN, int WM, int WN, int NS>
-__global__ void __launch_bounds__(WM * WN * 64)
+__global__ void __launch_bounds__(WM * WN * 64, conv_waves_per_simd(BM, BN, WM * WN, NS))
 conv_igemm_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource
                                       // type and builtins below do not exist for the x86 target)
@@ -75,15 +90,15 @@ conv_igemm_kernel(const ConvArgs p) {
     constexpr int B_INSTR = BN / 8;
     constexpr int A_PER = A_INSTR / NW;
     constexpr int B_PER = (B_INSTR + NW - 1) / NW;
+    constexpr int LPS = A_PER + B_PER;              // loads per slab per wave (uniform)
     static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
-    static_assert(NS >= 2 && (NS - 2) * (A_PER + B_PER) < 64, "vmcnt is a 6-bit counter");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
-
-    // every wave issues exactly A_PER + B_PER loads per slab (uniform vmcnt bookkeeping); when
-    // BN/8 does not divide by the wave count the surplus loads are out-of-range (zeros) and land
-    // in one shared 1 KiB dump area behind the last stage
-    constexpr int STAGE_LDS = STAGE;
+    static_assert(NS >= 2 && (NS - 2) * LPS < 64, "vmcnt is a 6-bit counter");
+    // every wave issues exactly LPS loads per slab (uniform vmcnt bookkeeping); when BN/8 does
+    // not divide by the wave count the surplus loads are out-of-range (zeros) and land in one
+    // shared 1 KiB dump area behind the last stage
     constexpr int DUMP_OFF = NS * STAGE;
+    constexpr int BIAS_OFF = DUMP_OFF + 1024;       // BN fp32 biases of this stream's N tile
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lds_char* const smem = (lds_char*)smem_generic;
@@ -93,84 +108,100 @@ conv_igemm_kernel(const ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // ---- XCD-aware tile mapping (bijective; block b runs on XCD b % 8) -----------------
-    int tile_m, tile_n;
+    // ---- persistent streams: a workgroup owns one N tile and a contiguous run of M tiles ------
+    // XCD-aware: block b runs on XCD b % 8; streams are renumbered so that consecutive streams
+    // (neighbouring M ranges and the N tiles that share their A rows) sit behind the same L2.
+    int sid;
     {
         const int bid = blockIdx.x, nwg = gridDim.x;
         const int xcd = bid & 7, slot = bid >> 3;
         const int q = nwg >> 3, r = nwg & 7;
-        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-        tile_n = lin % p.tiles_n;
-        tile_m = lin / p.tiles_n;
+        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tile_n = sid % p.tiles_n;
+    const int first_tile = (sid / p.tiles_n) * p.tiles_per_stream;
+    const int my_tiles = min(p.tiles_per_stream, p.tiles_m - first_tile);
+    if (my_tiles <= 0) return;
+    const int n0 = tile_n * BN;
+    const int KT = p.k_pad >> 6;
+    const int total_steps = my_tiles * KT;
 
-    // ---- buffer descriptors (wave-uniform, built from scalars only) ---------------------
-    // A: based at the tile's first pixel minus the conv padding, so every in-range tap of
-    // every row of the tile has a small non-negative byte offset.
-    long long base_px;
-    {
-        const int b0 = m0 / p.HoWo;
-        const int rem0 = m0 - b0 * p.HoWo;
-        const int oy0 = rem0 / p.Wo;
-        const int ox0 = rem0 - oy0 * p.Wo;
-        base_px = (long long)(b0 * p.H + oy0 * p.stride - p.pad) * p.W + (ox0 * p.stride - p.pad);
-    }
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.in + base_px * p.ld_in), 0, kNumRecords, 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.wgt + (size_t)n0 * p.k_pad), 0, kNumRecords, 0x00020000);
-
-    // ---- loader geometry ---------------------------------------------------------------
+    // ---- weight side: fixed for the whole stream -------------------------------------------
     const int lr = lane >> 3;              // row inside an 8-row load instruction (== row & 7)
     const int jj = (lane & 7) ^ lr;        // swizzled source chunk inside the 128-byte K slab
-
-    unsigned a_off[A_PER];                 // byte offset of the row's (tap 0, channel 0) from the A base
-    uint32_t a_mask[A_PER];                // bit t set: tap t of this row is inside the image
-    const int kh = p.ntaps / p.kw;
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-        const int row = (i * NW + wave) * 8 + lr;
-        const int m = m0 + row;
-        uint32_t mask = 0;
-        unsigned off = 0;
-        if (m < p.M) {
-            const int b = m / p.HoWo;
-            const int rem = m - b * p.HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            const int iy0 = oy * p.stride - p.pad;
-            const int ix0 = ox * p.stride - p.pad;
-            const long long px = (long long)(b * p.H + iy0) * p.W + ix0;
-            off = (unsigned)((px - base_px) * p.ld_in * 2);
-#pragma unroll
-            for (int r = 0; r < 3; ++r)          // kernels are 1x1 or 3x3 (planner enforces it)
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-                    if (r < kh && s < p.kw && (unsigned)(iy0 + r) < (unsigned)p.H &&
-                        (unsigned)(ix0 + s) < (unsigned)p.W)
-                        mask |= 1u << (r * p.kw + s);
-        }
-        a_off[i] = off;
-        a_mask[i] = mask;
-    }
-    unsigned b_off[B_PER];                 // byte offset of (row, chunk jj) from the B base; soffset adds kt*128
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.wgt + (size_t)n0 * p.k_pad), 0, kNumRecords, 0x00020000);
+    unsigned b_off[B_PER];                 // byte offset of (row, chunk jj); the slab adds kt*128 as SGPR offset
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
         const int row = (i * NW + wave) * 8 + lr;
         b_off[i] = (row < BN && n0 + row < p.n_rows) ? (unsigned)(row * p.k_pad + jj * 8) * 2u : kOOB;
     }
+    for (int i = tid; i < BN; i += NW * 64)
+        *(__attribute__((address_space(3))) float*)(smem + BIAS_OFF + i * 4) =
+            (n0 + i < p.n_rows) ? p.bias[n0 + i] : 0.f;
+    __syncthreads();
 
-    // per-lane position inside K: chunk c8 of tap (tr, ts)
-    int c8 = jj, tap = 0, tr = 0, ts = 0;
-    while (c8 >= p.C8) {
-        c8 -= p.C8;
-        ++tap;
-        if (++ts == p.kw) { ts = 0; ++tr; }
-    }
+    // ---- activation side: loader state of the tile whose slabs are being issued ---------------
+    __amdgpu_buffer_rsrc_t a_rsrc = b_rsrc;
+    unsigned a_off[A_PER];                 // byte offset of the row's (tap 0, channel 0) from the A base
+    uint32_t a_mask[A_PER];                // bit t set: tap t of this row is inside the image
+    int c8 = 0, tap = 0, tr = 0, ts = 0;   // this lane's position inside K
+    int l_kt = KT, l_tile = first_tile - 1;
+    const int kh = p.ntaps / p.kw;
 
-    auto stage = [&](int kt, int buf) {
-        lds_char* sA = smem + buf * STAGE_LDS;
+    auto init_loader_tile = [&](int tile_m) {
+        const int m0 = tile_m * BM;
+        // descriptor based at the tile's first pixel minus the conv padding: every in-range tap
+        // of every row of the tile has a small non-negative byte offset
+        const int b0 = m0 / p.HoWo;
+        const int rem0 = m0 - b0 * p.HoWo;
+        const int oy0 = rem0 / p.Wo;
+        const int ox0 = rem0 - oy0 * p.Wo;
+        const long long base_px = (long long)(b0 * p.H + oy0 * p.stride - p.pad) * p.W + (ox0 * p.stride - p.pad);
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + base_px * p.ld_in), 0, kNumRecords, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int row = (i * NW + wave) * 8 + lr;
+            const int m = m0 + row;
+            uint32_t mask = 0;
+            unsigned off = 0;
+            if (m < p.M) {
+                const int b = m / p.HoWo;
+                const int rem = m - b * p.HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad;
+                const int ix0 = ox * p.stride - p.pad;
+                const long long px = (long long)(b * p.H + iy0) * p.W + ix0;
+                off = (unsigned)((px - base_px) * p.ld_in * 2);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)          // kernels are 1x1 or 3x3 (planner enforces it)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        if (r < kh && s < p.kw && (unsigned)(iy0 + r) < (unsigned)p.H &&
+                            (unsigned)(ix0 + s) < (unsigned)p.W)
+                            mask |= 1u << (r * p.kw + s);
+            }
+            a_off[i] = off;
+            a_mask[i] = mask;
+        }
+        c8 = jj; tap = 0; tr = 0; ts = 0;
+        while (c8 >= p.C8) {
+            c8 -= p.C8;
+            ++tap;
+            if (++ts == p.kw) { ts = 0; ++tr; }
+        }
+    };
+
+    // issue the loads of the next slab (crossing into the stream's next tile when needed)
+    auto issue = [&](int buf) {
+        if (l_kt == KT) {
+            ++l_tile;
+            init_loader_tile(l_tile);
+            l_kt = 0;
+        }
+        lds_char* sA = smem + buf * STAGE;
         lds_char* sB = sA + A_BYTES;
         const unsigned tapoff = (unsigned)((tr * p.W + ts) * p.ld_in + c8 * 8) * 2u;
         const uint32_t bit = (tap < p.ntaps) ? (1u << (tap & 31)) : 0u;
@@ -179,20 +210,20 @@ conv_igemm_kernel(const ConvArgs p) {
             const unsigned voff = (a_mask[i] & bit) ? a_off[i] + tapoff : kOOB;
             MDHIP_BLDS16(a_rsrc, sA + (i * NW + wave) * 1024, voff, 0);
         }
-        const int soff = kt * 128;
+        const int soff = l_kt * 128;
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int instr = i * NW + wave;
             lds_char* dst = (instr < B_INSTR) ? sB + instr * 1024 : smem + DUMP_OFF;
             MDHIP_BLDS16(b_rsrc, dst, b_off[i], soff);
         }
-        // advance this lane's K position by one slab (8 chunks)
-        c8 += 8;
+        c8 += 8;                           // advance this lane's K position by one slab
         while (c8 >= p.C8) {
             c8 -= p.C8;
             ++tap;
             if (++ts == p.kw) { ts = 0; ++tr; }
         }
+        ++l_kt;
     };
 
     // ---- fragment read offsets ---------------------------------------------------------
@@ -209,25 +240,62 @@ conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = p.k_pad >> 6;
-    // prologue: slabs 0 .. NS-2 in flight
+    // ---- epilogue: lane holds channels n..n+3 of pixel m --------------------------------
+    auto epilogue = [&](int tile_m) {
+        const int m0 = tile_m * BM;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * TM + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nl = wn * TN + j * 16 + (lane >> 4) * 4;
+                const int n = n0 + nl;
+                const float4 bv = *(const __attribute__((address_space(3))) float4*)(smem + BIAS_OFF + nl * 4);
+                float v0 = acc[i][j][0] + bv.x;
+                float v1 = acc[i][j][1] + bv.y;
+                float v2 = acc[i][j][2] + bv.z;
+                float v3 = acc[i][j][3] + bv.w;
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m >= p.M || n >= p.N) continue;
+                if (p.act) {
+                    v0 = silu_f32(v0); v1 = silu_f32(v1); v2 = silu_f32(v2); v3 = silu_f32(v3);
+                }
+                if (p.res) {
+                    const uint2 rv = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
+                    v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff));
+                    v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
+                    v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff));
+                    v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+                }
+                if (p.out_f32) {
+                    *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v0, v1, v2, v3);
+                } else {
+                    uint2 o;
+                    o.x = pack2_bf16(v0, v1);
+                    o.y = pack2_bf16(v2, v3);
+                    *(uint2*)((uint16_t*)p.out + (size_t)m * p.ld_out + n) = o;
+                }
+            }
+        }
+    };
+
+    // ---- software pipeline over (tile, slab) steps ----------------------------------------
+    int issued = 0;
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
-        if (st < KT) stage(st, st);
+        if (issued < total_steps) { issue(st); ++issued; }
 
-    int cur = 0;                 // ring slot of slab kt
+    int cur = 0;                 // ring slot of the slab being consumed
     int nxt = NS - 1;            // ring slot the next issued slab goes to
-    for (int kt = 0; kt < KT; ++kt) {
-        // own loads of slab kt have landed; up to NS-2 younger slabs may stay in flight
-        if (kt + (NS - 2) < KT) {
-            wait_vmcnt<(NS - 2) * (A_PER + B_PER)>();
-        } else {
-            wait_vmcnt<0>();     // tail: fewer slabs are outstanding than the steady-state count
-        }
+    int c_kt = 0, c_tile = first_tile;
+    for (int step = 0; step < total_steps; ++step) {
+        // this wave's loads of the current slab have landed; up to NS-2 younger slabs stay in flight
+        if (step + (NS - 2) < total_steps) wait_vmcnt<(NS - 2) * LPS>();
+        else wait_vmcnt<0>();    // tail: fewer slabs are outstanding than the steady-state count
         __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < KT) stage(kt + NS - 1, nxt);
+        if (issued < total_steps) { issue(nxt); ++issued; }
 
-        const lds_char* sbase = smem + cur * STAGE_LDS;
+        const lds_char* sbase = smem + cur * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int choff = frag_ch0 ^ (kk * 64);
@@ -244,43 +312,13 @@ conv_igemm_kernel(const ConvArgs p) {
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
+        if (++c_kt == KT) {      // tile finished: write it out while the next tile's slabs stream in
+            epilogue(c_tile);
+            c_kt = 0;
+            ++c_tile;
+        }
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-    }
-
-    // ---- epilogue: lane holds channels n..n+3 of pixel m --------------------------------
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * TM + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            const float4 bv = *(const float4*)(p.bias + n);
-            float v0 = acc[i][j][0] + bv.x;
-            float v1 = acc[i][j][1] + bv.y;
-            float v2 = acc[i][j][2] + bv.z;
-            float v3 = acc[i][j][3] + bv.w;
-            if (p.act) {
-                v0 = silu_f32(v0); v1 = silu_f32(v1); v2 = silu_f32(v2); v3 = silu_f32(v3);
-            }
-            if (p.res) {
-                const uint2 rv = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
-                v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
-                v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
-            }
-            if (p.out_f32) {
-                *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v0, v1, v2, v3);
-            } else {
-                uint2 o;
-                o.x = pack2_bf16(v0, v1);
-                o.y = pack2_bf16(v2, v3);
-                *(uint2*)((uint16_t*)p.out + (size_t)m * p.ld_out + n) = o;
-            }
-        }
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -321,9 +359,8 @@ conv_igemm_kernel(const ConvArgs p) {
 
 static const ConvCfg g_cfgs[] = {
 #define X(id, bm, bn, wm, wn, ns)                                                                   \
-    {bm, bn, (wm) * (wn) * 64,                                                                      \
-     (size_t)(ns) * ((bm) + (bn)) * 128 + 1024,                                                     \
-     #bm "x" #bn "/" #wm "x" #wn "/s" #ns},
+    {bm, bn, (wm) * (wn) * 64, (size_t)conv_lds_bytes(bm, bn, ns),                                  \
+     conv_blocks_per_cu(bm, bn, (wm) * (wn), ns), #bm "x" #bn "/" #wm "x" #wn "/s" #ns},
     MDHIP_CONV_CFGS(X)
 #undef X
 };
@@ -347,8 +384,15 @@ hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     const ConvCfg& c = g_cfgs[cfg];
     ConvArgs p = a;
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;
-    const int tiles_m = (a.M + c.bm - 1) / c.bm;
-    const dim3 grid((unsigned)(tiles_m * p.tiles_n));
+    p.tiles_m = (a.M + c.bm - 1) / c.bm;
+    // persistent streams: about as many workgroups as fit on the chip at once, each walking a
+    // contiguous run of M tiles with its load pipeline running across tile boundaries
+    const int per_cu = c.blocks_per_cu;
+    int m_streams = std::max(1, (256 * per_cu) / p.tiles_n);
+    m_streams = std::min(m_streams, p.tiles_m);
+    p.tiles_per_stream = (p.tiles_m + m_streams - 1) / m_streams;
+    m_streams = (p.tiles_m + p.tiles_per_stream - 1) / p.tiles_per_stream;
+    const dim3 grid((unsigned)(m_streams * p.tiles_n));
     switch (cfg) {
 #define X(id, bm, bn, wm, wn, ns)                                                                 \
     case id:                                                                                      \

@@ -43,12 +43,13 @@ struct ConvArgs {
     int stride, pad;
     int act;                // 1 = SiLU
     int out_f32;            // 1 = fp32 output, no rounding (Detect logits)
-    int tiles_n;
+    int tiles_n, tiles_m, tiles_per_stream;   // filled by conv_launch
 };
 
 struct ConvCfg {
     int bm, bn, threads;
     size_t lds_bytes;
+    int blocks_per_cu;      // residency the kernel is compiled for (LDS- and wave-limited)
     const char* name;
 };
 
