@@ -51,12 +51,20 @@ typedef __attribute__((address_space(3))) char lds_char;
 constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records
 constexpr int kNumRecords = 0x7fffffff;
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// SiLU = x * sigmoid(x): v_mul, v_exp, v_add, v_rcp, v_mul (each <= 1 ulp: far inside the bf16
+// rounding that follows)
 __device__ __forceinline__ float silu_f32(float x) {
-    return x / (1.0f + __expf(-x));
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// two fp32 -> packed bf16, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
-    return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    const f32x2_t v = {a, b};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return *(const uint32_t*)&r;
 }
 
 template <int N>
@@ -108,20 +116,20 @@ conv_igemm_kernel(const ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // ---- persistent streams: a workgroup owns one N tile and a contiguous run of M tiles ------
-    // XCD-aware: block b runs on XCD b % 8; streams are renumbered so that consecutive streams
-    // (neighbouring M ranges and the N tiles that share their A rows) sit behind the same L2.
-    int sid;
-    {
-        const int bid = blockIdx.x, nwg = gridDim.x;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int tile_n = sid % p.tiles_n;
-    const int first_tile = (sid / p.tiles_n) * p.tiles_per_stream;
-    const int my_tiles = min(p.tiles_per_stream, p.tiles_m - first_tile);
+    // ---- persistent streams ------------------------------------------------------------------
+    // Block b runs on XCD b % 8.  Each XCD owns one contiguous range of M tiles; inside the XCD the
+    // streams interleave over that range (stream s takes tiles s, s+S, s+2S, ...), so at any moment
+    // the workgroups behind one L2 work on neighbouring tiles: the 3x3 halo rows and the A rows
+    // shared by the N tiles are L2 hits instead of fabric traffic.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_n = slot % p.tiles_n;
+    const int ms = slot / p.tiles_n;                       // M stream index inside the XCD
+    const int xcd_first = xcd * p.tiles_per_xcd;
+    const int xcd_tiles = min(p.tiles_per_xcd, p.tiles_m - xcd_first);
+    const int my_tiles = (xcd_tiles > ms) ? (xcd_tiles - ms + p.m_streams - 1) / p.m_streams : 0;
     if (my_tiles <= 0) return;
+    const int first_tile = xcd_first + ms;
+    const int tile_step = p.m_streams;
     const int n0 = tile_n * BN;
     const int KT = p.k_pad >> 6;
     const int total_steps = my_tiles * KT;
@@ -147,7 +155,7 @@ conv_igemm_kernel(const ConvArgs p) {
     unsigned a_off[A_PER];                 // byte offset of the row's (tap 0, channel 0) from the A base
     uint32_t a_mask[A_PER];                // bit t set: tap t of this row is inside the image
     int c8 = 0, tap = 0, tr = 0, ts = 0;   // this lane's position inside K
-    int l_kt = KT, l_tile = first_tile - 1;
+    int l_kt = KT, l_tile = first_tile - tile_step;
     const int kh = p.ntaps / p.kw;
 
     auto init_loader_tile = [&](int tile_m) {
@@ -197,7 +205,7 @@ conv_igemm_kernel(const ConvArgs p) {
     // issue the loads of the next slab (crossing into the stream's next tile when needed)
     auto issue = [&](int buf) {
         if (l_kt == KT) {
-            ++l_tile;
+            l_tile += tile_step;
             init_loader_tile(l_tile);
             l_kt = 0;
         }
@@ -315,7 +323,7 @@ conv_igemm_kernel(const ConvArgs p) {
         if (++c_kt == KT) {      // tile finished: write it out while the next tile's slabs stream in
             epilogue(c_tile);
             c_kt = 0;
-            ++c_tile;
+            c_tile += tile_step;
         }
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
@@ -385,14 +393,11 @@ hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;
     p.tiles_m = (a.M + c.bm - 1) / c.bm;
-    // persistent streams: about as many workgroups as fit on the chip at once, each walking a
-    // contiguous run of M tiles with its load pipeline running across tile boundaries
-    const int per_cu = c.blocks_per_cu;
-    int m_streams = std::max(1, (256 * per_cu) / p.tiles_n);
-    m_streams = std::min(m_streams, p.tiles_m);
-    p.tiles_per_stream = (p.tiles_m + m_streams - 1) / m_streams;
-    m_streams = (p.tiles_m + p.tiles_per_stream - 1) / p.tiles_per_stream;
-    const dim3 grid((unsigned)(m_streams * p.tiles_n));
+    // persistent streams: about as many workgroups as fit on the chip at once (32 CUs per XCD);
+    // the load pipeline of a stream runs across its tile boundaries
+    p.tiles_per_xcd = (p.tiles_m + 7) / 8;
+    p.m_streams = std::max(1, std::min(p.tiles_per_xcd, (32 * c.blocks_per_cu) / p.tiles_n));
+    const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
     switch (cfg) {
 #define X(id, bm, bn, wm, wn, ns)                                                                 \
     case id:                                                                                      \

@@ -43,7 +43,7 @@ struct ConvArgs {
     int stride, pad;
     int act;                // 1 = SiLU
     int out_f32;            // 1 = fp32 output, no rounding (Detect logits)
-    int tiles_n, tiles_m, tiles_per_stream;   // filled by conv_launch
+    int tiles_n, tiles_m, tiles_per_xcd, m_streams;   // filled by conv_launch
 };
 
 struct ConvCfg {

@@ -16,7 +16,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout 300 rocprofv3 --pmc $SET -d "$R/gpurun_out/pmc/${TAG}_p$i" -o p --output-format csv -- python "$R/tools/pmc_probe.py" "$OP" "$CFG" 3 > "$R/gpurun_out/pmc/${TAG}_p$i.log" 2>&1
 done
 cd "$R"
-python - "$TAG" <<'PY'
+python tools/pmc_report.py "$TAG" > "gpurun_out/pmc/${TAG}_summary.txt"; cat "gpurun_out/pmc/${TAG}_summary.txt"; cat > /dev/null <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]
 acc = collections.defaultdict(list)
