@@ -1,0 +1,570 @@
+"""
+Batch driver: the image loop of the reference (megadetector/detection/run_detector_batch.py) on
+top of the HIP detector, emitting the same MegaDetector JSON.
+
+Mirrored entry points (same names, argument meaning and failure conventions):
+  load_and_run_detector_batch   reference :1062-1439
+  _process_batch                reference :680-831   (batched path; threshold applied afterwards :766)
+  _process_image                reference :937-1056  (per-image path; threshold forwarded :988-994)
+  write_checkpoint / load_checkpoint   reference :1465 / :1497
+  write_results_to_file         reference :1546-1662
+  main (CLI)                    reference :1763-2186 (the options that touch this path)
+New here (spec = reference notebooks/manage_local_batch.py:496-964):
+  run_sharded                   one spawned worker process per GPU, balanced `i % G` sharding of the
+                                image list, host-side merge with duplicate/missing checks -- no
+                                collectives; output identical to the 1-GPU result.
+
+Loader workers are threads, never forked processes: a forked child of a process that has touched
+HIP is undefined behaviour (the reference forks before loading the model, run_detector_batch.py:
+545-557; `--use_threads_for_queue` :1814 is its safe variant and the only one offered here).
+"""
+
+import argparse
+import copy
+import json
+import os
+import queue
+import shutil
+import sys
+import threading
+import time
+from datetime import datetime
+
+from . import run_detector
+from .constants import FAILURE_IMAGE_OPEN, FAILURE_INFER, DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD
+from .constants import DEFAULT_DETECTOR_LABEL_MAP
+
+# reference run_detector_batch.py:86-119
+default_loaders = 4
+default_preprocess_on_image_queue = False
+max_queue_size = 10
+current_format_version = '1.6'
+verbose = False
+
+image_extensions = ('.jpg', '.jpeg', '.gif', '.png')           # reference ct_utils.py:30
+EXIF_IMAGE_ROTATIONS = {3: 180, 6: 270, 8: 90}                  # reference visualization_utils.py
+
+
+# --------------------------------------------------------------------------------------------
+# host I/O helpers
+# --------------------------------------------------------------------------------------------
+def load_image(input_file, ignore_exif_rotation=False):
+    """PIL decode to RGB with EXIF rotation (reference visualization_utils.py:103-175, :306)."""
+    from PIL import Image
+    image = Image.open(input_file)
+    if image.mode not in ('RGBA', 'RGB', 'L', 'I;16'):
+        raise AttributeError('Image {} uses unsupported mode {}'.format(input_file, image.mode))
+    if image.mode in ('RGBA', 'L'):
+        image = image.convert(mode='RGB')
+    if not ignore_exif_rotation:
+        try:
+            exif = image._getexif()
+            orientation = exif.get(274, None)
+            if orientation is not None and orientation != 1:
+                assert orientation in EXIF_IMAGE_ROTATIONS, 'Mirrored rotations are not supported'
+                image = image.rotate(EXIF_IMAGE_ROTATIONS[orientation], expand=True)
+        except Exception:
+            pass
+    image.load()
+    return image
+
+
+def is_image_file(s):
+    return os.path.splitext(s)[1].lower() in image_extensions
+
+
+def find_images(dirname, recursive=False):
+    """reference path_utils.py:525 (sorted list of image files)"""
+    found = []
+    if recursive:
+        for root, _, files in os.walk(dirname):
+            found += [os.path.join(root, f) for f in files if is_image_file(f)]
+    else:
+        found = [os.path.join(dirname, f) for f in os.listdir(dirname) if is_image_file(f)]
+    return sorted(found)
+
+
+def parse_kvp_list(items, kv_separator='='):
+    """reference ct_utils.py:921: ['a=b','c=d'] (or 'a=b,c=d') -> {'a':'b','c':'d'}"""
+    if items is None:
+        return {}
+    if isinstance(items, str):
+        items = [s for s in items.split(',') if s]
+    d = {}
+    for item in items:
+        if kv_separator not in item:
+            raise ValueError('Illegal key-value pair: {}'.format(item))
+        k, v = item.split(kv_separator, 1)
+        d[k.strip()] = v.strip()
+    return d
+
+
+def write_json(path, content, indent=1):
+    """reference ct_utils.py:210-251 (force_str=True)"""
+    parent = os.path.dirname(path)
+    if parent:
+        os.makedirs(parent, exist_ok=True)
+    with open(path, 'w', newline='\n', encoding='utf-8') as f:
+        json.dump(content, f, indent=indent, default=str, ensure_ascii=True)
+
+
+def _sort_by_key(items, key, reverse=False):
+    """reference ct_utils.py:509 (None sorts as smallest)"""
+    return sorted(items, key=lambda d: (d[key] is not None, d[key]), reverse=reverse)
+
+
+# --------------------------------------------------------------------------------------------
+# per-batch / per-image processing
+# --------------------------------------------------------------------------------------------
+def _group_into_batches(items, batch_size):
+    """reference :657"""
+    if batch_size <= 0:
+        raise ValueError('Batch size must be positive')
+    return [items[i:i + batch_size] for i in range(0, len(items), batch_size)]
+
+
+def _add_image_metadata(result, image, include_image_size, include_image_timestamp):
+    if isinstance(image, dict):
+        image = image['img_original_pil']
+    if image is None:
+        return
+    if include_image_size:
+        result['width'] = image.width
+        result['height'] = image.height
+    if include_image_timestamp:
+        dt = None
+        try:
+            exif = image.getexif()
+            dt = exif.get(36867) or exif.get(306)       # DateTimeOriginal / DateTime
+        except Exception:
+            pass
+        result['datetime'] = dt
+
+
+def _process_batch(image_items_batch, detector, confidence_threshold, quiet=False, image_size=None,
+                   include_image_size=False, include_image_timestamp=False, include_exif_tags=None,
+                   augment=False):
+    """
+    reference :680-831.  Items are file names or (file, image, producer_id) tuples.  As in the
+    reference, the batched detector call receives neither the threshold nor image_size/augment
+    (:751-754); the confidence threshold is applied to its output (:766-767).
+    """
+    valid_images, valid_names, batch_results = [], [], []
+    for item in image_items_batch:
+        if isinstance(item, str):
+            try:
+                image = load_image(item)
+            except Exception as e:
+                print('Image {} cannot be loaded: {}'.format(item, str(e)))
+                batch_results.append({'file': item, 'failure': FAILURE_IMAGE_OPEN})
+                continue
+            name = item
+        else:
+            assert len(item) == 3
+            name, image, _ = item
+        valid_images.append(image)
+        valid_names.append(name)
+
+    valid_results = []
+    if valid_images:
+        try:
+            dets = detector.generate_detections_one_batch(valid_images, valid_names, verbose=verbose)
+            assert len(dets) == len(valid_images)
+            for i, r in enumerate(dets):
+                assert valid_names[i] == r['file']
+                if 'failure' not in r:
+                    r['detections'] = [d for d in r['detections'] if d['conf'] >= confidence_threshold]
+                    if include_image_size or include_image_timestamp:
+                        _add_image_metadata(r, valid_images[i], include_image_size, include_image_timestamp)
+                else:
+                    print('Warning: within-batch processing failure for image {}'.format(r['file']))
+                valid_results.append(r)
+        except Exception as e:
+            print('Batch processing failure for {} images: {}'.format(len(valid_images), str(e)))
+            valid_results = [{'file': n, 'failure': FAILURE_INFER} for n in valid_names]
+    batch_results.extend(valid_results)
+    return batch_results
+
+
+def _process_image(im_file, detector, confidence_threshold, image=None, quiet=False, image_size=None,
+                   include_image_size=False, include_image_timestamp=False, include_exif_tags=None,
+                   augment=False):
+    """reference :937-1056 (the un-batched path: threshold, image_size and augment ARE forwarded)"""
+    if not quiet:
+        print('Processing image {}'.format(im_file))
+    if image is None:
+        try:
+            image = load_image(im_file)
+        except Exception as e:
+            if not quiet:
+                print('Image {} cannot be loaded: {}'.format(im_file, str(e)))
+            return {'file': im_file, 'failure': FAILURE_IMAGE_OPEN}
+    try:
+        result = detector.generate_detections_one_image(image, im_file, detection_threshold=confidence_threshold,
+                                                        image_size=image_size, augment=augment, verbose=verbose)
+    except Exception as e:
+        if not quiet:
+            print('Image {} cannot be processed: {}'.format(im_file, str(e)))
+        return {'file': im_file, 'failure': FAILURE_INFER}
+    if 'failure' not in result or result.get('failure') is None:
+        _add_image_metadata(result, image, include_image_size, include_image_timestamp)
+    return result
+
+
+# --------------------------------------------------------------------------------------------
+# checkpoints (reference :1465-1520)
+# --------------------------------------------------------------------------------------------
+def write_checkpoint(checkpoint_path, results):
+    assert checkpoint_path is not None
+    tmp = None
+    if os.path.isfile(checkpoint_path):
+        tmp = checkpoint_path + '_tmp'
+        shutil.copyfile(checkpoint_path, tmp)
+    write_json(checkpoint_path, {'checkpoint': results})
+    if tmp is not None:
+        try:
+            os.remove(tmp)
+        except Exception as e:
+            print('Warning: error removing backup checkpoint file {}:\n{}'.format(tmp, str(e)))
+
+
+def load_checkpoint(checkpoint_path):
+    print('Loading previous results from checkpoint file {}'.format(checkpoint_path))
+    with open(checkpoint_path, 'r') as f:
+        data = json.load(f)
+    if 'checkpoint' not in data:
+        raise ValueError('Checkpoint file {} is missing "checkpoint" field'.format(checkpoint_path))
+    print('Restored {} entries from the checkpoint {}'.format(len(data['checkpoint']), checkpoint_path))
+    return data['checkpoint']
+
+
+# --------------------------------------------------------------------------------------------
+# image queue (threads) -- reference :124-200 producers, :203-455 consumer, :461-650 driver
+# --------------------------------------------------------------------------------------------
+def _producer(q, file_q, preprocessor, image_size, producer_id):
+    while True:
+        try:
+            im_file = file_q.get_nowait()
+        except queue.Empty:
+            break
+        try:
+            image = load_image(im_file)
+            if preprocessor is not None:
+                image = preprocessor.preprocess_image(image, image_id=im_file, image_size=image_size)
+        except Exception as e:
+            print('Producer process: image {} cannot be loaded:\n{}'.format(im_file, str(e)))
+            image = FAILURE_IMAGE_OPEN
+        q.put((im_file, image, producer_id))
+    q.put(None)
+
+
+def _run_detector_with_image_queue(image_files, detector, confidence_threshold, quiet, image_size,
+                                   include_image_size, include_image_timestamp, augment, loader_workers,
+                                   preprocess_on_image_queue, batch_size, on_results):
+    q = queue.Queue(max_queue_size)
+    file_q = queue.Queue()
+    for f in image_files:
+        file_q.put(f)
+    preprocessor = None
+    if preprocess_on_image_queue:
+        from .detector import HIPDetector
+        preprocessor = HIPDetector('synthetic', {'preprocess_only': True})
+        preprocessor.default_image_size = detector.default_image_size
+        preprocessor.letterbox_stride = detector.letterbox_stride
+    n_workers = max(1, min(loader_workers, len(image_files)))
+    threads = [threading.Thread(target=_producer, args=(q, file_q, preprocessor, image_size, i), daemon=True)
+               for i in range(n_workers)]
+    for t in threads:
+        t.start()
+    finished = 0
+    pending = []
+
+    def flush():
+        if pending:
+            if batch_size > 1:
+                on_results(_process_batch(list(pending), detector, confidence_threshold, quiet, image_size,
+                                          include_image_size, include_image_timestamp, None, augment))
+            else:
+                on_results([_process_image(f, detector, confidence_threshold, image=im, quiet=quiet,
+                                           image_size=image_size, include_image_size=include_image_size,
+                                           include_image_timestamp=include_image_timestamp, augment=augment)
+                            for f, im, _ in pending])
+            pending.clear()
+
+    while finished < n_workers:
+        item = q.get()
+        if item is None:
+            finished += 1
+            continue
+        if isinstance(item[1], str):
+            on_results([{'file': item[0], 'failure': item[1]}])
+            continue
+        pending.append(item)
+        if len(pending) >= max(1, batch_size):
+            flush()
+    flush()
+    for t in threads:
+        t.join()
+
+
+# --------------------------------------------------------------------------------------------
+# main entry point
+# --------------------------------------------------------------------------------------------
+def _resolve_image_list(image_file_names):
+    """reference :1150-1190: list | single image | folder | .json / .txt list file"""
+    if isinstance(image_file_names, str):
+        s = image_file_names
+        if os.path.isdir(s):
+            return find_images(s, recursive=True)
+        if is_image_file(s):
+            return [s]
+        if s.lower().endswith('.json'):
+            with open(s, 'r') as f:
+                return list(json.load(f))
+        if s.lower().endswith('.txt'):
+            with open(s, 'r') as f:
+                return [ln.strip() for ln in f if ln.strip()]
+        raise ValueError('Illegal image_file_names value {}'.format(s))
+    return list(image_file_names)
+
+
+def load_and_run_detector_batch(model_file, image_file_names, checkpoint_path=None,
+                                confidence_threshold=DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD,
+                                checkpoint_frequency=-1, results=None, n_cores=1, use_image_queue=False,
+                                quiet=False, image_size=None, class_mapping_filename=None,
+                                include_image_size=False, include_image_timestamp=False,
+                                include_exif_tags=None, augment=False, force_model_download=False,
+                                detector_options=None, loader_workers=default_loaders,
+                                preprocess_on_image_queue=default_preprocess_on_image_queue, batch_size=1,
+                                verbose_output=False, use_threads_for_queue=True, detector=None):
+    """
+    reference :1062-1439.  `detector` (extra, optional) injects an already constructed detector
+    object -- used by run_sharded and by the CPU tests of the loop with a stub detector.
+    Returns the list of per-image result dicts.
+    """
+    global verbose
+    verbose = bool(verbose_output)
+    if detector_options is None:
+        detector_options = {}
+    elif isinstance(detector_options, (list, str)):
+        detector_options = parse_kvp_list(detector_options)
+    else:
+        detector_options = dict(detector_options)
+    if class_mapping_filename is not None or include_exif_tags is not None:
+        raise NotImplementedError('class_mapping_filename / include_exif_tags are not part of the HIP hot path')
+    if n_cores is not None and n_cores > 1:
+        print('Warning: n_cores is ignored when running on a GPU (reference :1204)')
+    if results is None:
+        results = []
+    already_processed = set(r['file'] for r in results)
+    image_files = [f for f in _resolve_image_list(image_file_names) if f not in already_processed]
+    batch_size = max(1, int(batch_size))
+    if batch_size > 1:
+        detector_options['batch_size'] = batch_size           # reference :1227-1228
+
+    if detector is None:
+        t0 = time.time()
+        detector = run_detector.load_detector(model_file, force_model_download=force_model_download,
+                                              detector_options=detector_options, verbose=verbose)
+        print('Loaded model in {:.2f} seconds'.format(time.time() - t0))
+
+    since_checkpoint = [0]
+
+    def on_results(new_results):
+        results.extend(new_results)
+        since_checkpoint[0] += len(new_results)
+        if checkpoint_path is not None and checkpoint_frequency != -1 and \
+                since_checkpoint[0] >= checkpoint_frequency:
+            print('Writing a new checkpoint after having processed {} images since last restart'.format(len(results)))
+            write_checkpoint(checkpoint_path, results)
+            since_checkpoint[0] = 0
+
+    if use_image_queue:
+        _run_detector_with_image_queue(image_files, detector, confidence_threshold, quiet, image_size,
+                                       include_image_size, include_image_timestamp, augment, loader_workers,
+                                       preprocess_on_image_queue, batch_size, on_results)
+    elif batch_size > 1:
+        for batch in _group_into_batches(image_files, batch_size):
+            on_results(_process_batch(batch, detector, confidence_threshold, quiet, image_size,
+                                      include_image_size, include_image_timestamp, None, augment))
+    else:
+        for im_file in image_files:
+            on_results([_process_image(im_file, detector, confidence_threshold, quiet=quiet, image_size=image_size,
+                                       include_image_size=include_image_size,
+                                       include_image_timestamp=include_image_timestamp, augment=augment)])
+    return results
+
+
+def write_results_to_file(results, output_file, relative_path_base=None, detector_file=None, info=None,
+                          include_max_conf=False, custom_metadata=None, force_forward_slashes=True):
+    """reference :1546-1662: MegaDetector batch output format 1.6"""
+    out = []
+    for r in results:
+        r = copy.copy(r)
+        if relative_path_base is not None:
+            r['file'] = os.path.relpath(r['file'], start=relative_path_base)
+        if force_forward_slashes:
+            r['file'] = r['file'].replace('\\', '/')
+        if not include_max_conf:
+            r.pop('max_detection_conf', None)
+        out.append(r)
+    if info is None:
+        info = {'detection_completion_time': datetime.now().strftime('%Y-%m-%d %H:%M:%S'),
+                'format_version': current_format_version}
+        if detector_file is not None:
+            name = os.path.basename(detector_file)
+            info['detector'] = name
+            info['detector_metadata'] = run_detector.get_detector_metadata_from_version_string(
+                run_detector.get_detector_version_from_filename(name, verbose=True))
+        else:
+            info['detector'] = 'unknown'
+            info['detector_metadata'] = run_detector.get_detector_metadata_from_version_string('unknown')
+    elif detector_file is not None:
+        print('Warning (write_results_to_file): info struct and detector file supplied, ignoring detector file')
+    if custom_metadata is not None:
+        info['custom_metadata'] = custom_metadata
+    out = _sort_by_key(out, 'file')
+    for im in out:
+        if im.get('detections') is not None:
+            im['detections'] = _sort_by_key(im['detections'], 'conf', reverse=True)
+        if 'failure' in im:
+            assert im.get('detections') is None, 'Illegal failure/detection combination'
+            im['detections'] = None
+    final_output = {'images': out, 'detection_categories': DEFAULT_DETECTOR_LABEL_MAP, 'info': info}
+    write_json(output_file, final_output)
+    print('Output file saved at {}'.format(output_file))
+    return final_output
+
+
+# --------------------------------------------------------------------------------------------
+# multi-GPU: shard the image queue, one process per GPU, no collectives
+# --------------------------------------------------------------------------------------------
+def shard_image_list(image_files, n_shards):
+    """balanced split (reference ct_utils.py:499-503 'balanced' strategy: shard i gets files i, i+n, ...)"""
+    return [list(image_files[i::n_shards]) for i in range(n_shards)]
+
+
+def merge_shard_results(shard_results, expected_files=None):
+    """reference notebooks/manage_local_batch.py:930-964: concatenate, reject duplicates / omissions"""
+    merged, seen = [], set()
+    for res in shard_results:
+        for r in res:
+            if r['file'] in seen:
+                raise ValueError('duplicate result for {}'.format(r['file']))
+            seen.add(r['file'])
+            merged.append(r)
+    if expected_files is not None:
+        missing = [f for f in expected_files if f not in seen]
+        if missing:
+            raise ValueError('{} images have no result (first: {})'.format(len(missing), missing[0]))
+    return merged
+
+
+def _shard_worker(gpu, model_file, files, kwargs, out_q):
+    try:
+        opts = dict(kwargs.pop('detector_options', None) or {})
+        opts['device'] = 'cuda:{}'.format(gpu)
+        res = load_and_run_detector_batch(model_file, files, detector_options=opts, **kwargs)
+        out_q.put((gpu, res, None))
+    except Exception as e:        # the parent reports it; a dead shard must not hang the join
+        out_q.put((gpu, None, repr(e)))
+
+
+def run_sharded(model_file, image_file_names, n_gpus, **kwargs):
+    """
+    Runs load_and_run_detector_batch on n_gpus GPUs of one node: the image list is split
+    `i % n_gpus`, each shard runs in its own *spawned* process pinned to one GPU
+    (detector_options['device'] = 'cuda:g', reference pytorch_detector.py:853-858), results are
+    merged on the host.  There is no inter-GPU traffic.
+    """
+    import multiprocessing as mp
+    files = _resolve_image_list(image_file_names)
+    if n_gpus <= 1:
+        return load_and_run_detector_batch(model_file, files, **kwargs)
+    ctx = mp.get_context('spawn')
+    out_q = ctx.Queue()
+    shards = shard_image_list(files, n_gpus)
+    procs = []
+    for g in range(n_gpus):
+        p = ctx.Process(target=_shard_worker, args=(g, model_file, shards[g], dict(kwargs), out_q))
+        p.start()
+        procs.append(p)
+    got = {}
+    for _ in range(n_gpus):
+        g, res, err = out_q.get()
+        if err is not None:
+            for p in procs:
+                p.terminate()
+            raise RuntimeError('shard {} failed: {}'.format(g, err))
+        got[g] = res
+    for p in procs:
+        p.join()
+    return merge_shard_results([got[g] for g in range(n_gpus)], expected_files=files)
+
+
+# --------------------------------------------------------------------------------------------
+# CLI (reference :1763-2186, the options that concern this path)
+# --------------------------------------------------------------------------------------------
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='Run MegaDetector (HIP / MI355X path) on a batch of images')
+    ap.add_argument('detector_file', help='.pt checkpoint, known model name (MDV5A ...; resolved through the '
+                                          'environment variable of the same name) or "synthetic"')
+    ap.add_argument('image_file', help='image file, folder, or .json/.txt list of image paths')
+    ap.add_argument('output_file', help='output .json')
+    ap.add_argument('--recursive', action='store_true', default=True)
+    ap.add_argument('--output_relative_filenames', action='store_true')
+    ap.add_argument('--quiet', action='store_true')
+    ap.add_argument('--image_size', type=int, default=None)
+    ap.add_argument('--augment', action='store_true')
+    ap.add_argument('--use_image_queue', action='store_true')
+    ap.add_argument('--preprocess_on_image_queue', action='store_true')
+    ap.add_argument('--loader_workers', type=int, default=default_loaders)
+    ap.add_argument('--batch_size', type=int, default=1)
+    ap.add_argument('--threshold', type=float, default=DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD)
+    ap.add_argument('--checkpoint_frequency', type=int, default=-1)
+    ap.add_argument('--checkpoint_path', type=str, default=None)
+    ap.add_argument('--resume_from_checkpoint', type=str, default=None)
+    ap.add_argument('--include_max_conf', action='store_true')
+    ap.add_argument('--include_image_size', action='store_true')
+    ap.add_argument('--include_image_timestamp', action='store_true')
+    ap.add_argument('--detector_options', nargs='*', metavar='KEY=VALUE', default='')
+    ap.add_argument('--n_gpus', type=int, default=1, help='shard the image list over this many GPUs')
+    ap.add_argument('--verbose', action='store_true')
+    args = ap.parse_args(argv)
+
+    assert 0.0 <= args.threshold <= 1.0, 'Confidence threshold needs to be between 0 and 1'
+    assert args.output_file.endswith('.json'), 'output_file specified needs to end with .json'
+    results = None
+    checkpoint_path = args.checkpoint_path
+    if args.checkpoint_frequency > 0 and checkpoint_path is None:
+        checkpoint_path = os.path.join(os.path.dirname(os.path.abspath(args.output_file)),
+                                       'md_checkpoint_{}.json'.format(datetime.now().strftime('%Y%m%d%H%M%S')))
+    if args.resume_from_checkpoint:
+        results = load_checkpoint(args.resume_from_checkpoint)
+    files = _resolve_image_list(args.image_file)
+    print('{} image files found in the input'.format(len(files)))
+    kwargs = dict(checkpoint_path=checkpoint_path, confidence_threshold=args.threshold,
+                  checkpoint_frequency=args.checkpoint_frequency, use_image_queue=args.use_image_queue,
+                  quiet=args.quiet, image_size=args.image_size, include_image_size=args.include_image_size,
+                  include_image_timestamp=args.include_image_timestamp, augment=args.augment,
+                  detector_options=parse_kvp_list(args.detector_options), loader_workers=args.loader_workers,
+                  preprocess_on_image_queue=args.preprocess_on_image_queue, batch_size=args.batch_size,
+                  verbose_output=args.verbose)
+    t0 = time.time()
+    if args.n_gpus > 1:
+        results = run_sharded(args.detector_file, files, args.n_gpus, **kwargs)
+    else:
+        results = load_and_run_detector_batch(args.detector_file, files, results=results, **kwargs)
+    elapsed = time.time() - t0
+    print('Finished inference for {} images in {:.1f} s ({:.2f} images per second)'.format(
+        len(results), elapsed, len(results) / max(elapsed, 1e-9)))
+    base = os.path.abspath(args.image_file) if (args.output_relative_filenames and os.path.isdir(args.image_file)) else None
+    write_results_to_file(results, args.output_file, relative_path_base=base, detector_file=args.detector_file,
+                          include_max_conf=args.include_max_conf)
+    if checkpoint_path and os.path.isfile(checkpoint_path):
+        os.remove(checkpoint_path)
+        print('Deleted checkpoint file {}'.format(checkpoint_path))
+
+
+if __name__ == '__main__':
+    main()

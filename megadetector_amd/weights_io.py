@@ -53,6 +53,9 @@ def synthetic_weights(yaml=None, seed=0, gain=1.75, res_gain=0.6, bias_std=0.1,
                 wt = rng.standard_normal((na * (nc + 5), c_in, 1, 1), dtype=np.float32)
                 wt -= wt.mean(axis=1, keepdims=True)
                 wt *= np.float32(detect_gain / np.sqrt(c_in))
+                # box logits stay small: (2*sigmoid)^2 * anchor then gives boxes of 0.3x..2x the
+                # anchor instead of degenerate slivers
+                wt.reshape(na, nc + 5, c_in)[:, :4, :] *= np.float32(0.2)
                 b = np.zeros((na, nc + 5), dtype=np.float32)
                 b[:, 4] = detect_obj_bias
                 b[:, 5:] = rng.standard_normal((na, nc), dtype=np.float32) * np.float32(0.5)

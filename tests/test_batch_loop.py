@@ -1,0 +1,215 @@
+"""
+CPU tests of the host side of the path: the image loop, checkpoint/resume, the JSON writer and
+the multi-GPU sharding logic -- with a deterministic stub detector standing in for the GPU, and
+a world_size-2 gloo run of the one-process-per-GPU path.
+"""
+
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from megadetector_amd import run_detector_batch as RDB
+from megadetector_amd import run_detector
+
+
+class StubDetector:
+    """Deterministic fake of the 3-method detector interface (reference tf_detector.py:136 shows the
+    minimal duck type); detections are a pure function of the pixels, so any orchestration must
+    give identical output."""
+
+    default_image_size = 1280
+    letterbox_stride = 64
+
+    def __init__(self, fail_on=None):
+        self.fail_on = fail_on or set()
+        self.batches = []
+
+    def _one(self, img, name):
+        if isinstance(img, dict):
+            img = img['img_original']
+        a = np.asarray(img)
+        if a.ndim != 3:
+            return {'file': name, 'detections': None, 'failure': 'image access failure'}
+        s = int(a.astype(np.int64).sum())
+        dets = []
+        for k in range(s % 4 + 1):
+            conf = ((s >> (3 * k)) % 1000) / 1000.0
+            dets.append({'category': str(1 + (s + k) % 3), 'conf': conf,
+                         'bbox': [0.1 * k, 0.05, 0.2, 0.3]})
+        return {'file': name, 'detections': dets, 'max_detection_conf': max(d['conf'] for d in dets)}
+
+    def generate_detections_one_batch(self, imgs, names, detection_threshold=1e-5, image_size=None,
+                                      augment=False, verbose=False):
+        self.batches.append(len(imgs))
+        if any(n in self.fail_on for n in names):
+            raise RuntimeError('simulated device failure')
+        return [self._one(i, n) for i, n in zip(imgs, names)]
+
+    def generate_detections_one_image(self, img, name='unknown', detection_threshold=1e-5, image_size=None,
+                                      augment=False, verbose=False):
+        r = self._one(img, name)
+        if r.get('detections') is not None:
+            r['detections'] = [d for d in r['detections'] if d['conf'] >= detection_threshold]
+        return r
+
+
+@pytest.fixture()
+def image_dir(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    names = []
+    for i in range(11):
+        sub = tmp_path / ('cam%d' % (i % 3))
+        sub.mkdir(exist_ok=True)
+        p = sub / ('img_%02d.jpg' % i)
+        Image.fromarray(rng.integers(0, 256, (40 + i, 64, 3), dtype=np.uint8)).save(p, quality=95)
+        names.append(str(p))
+    bad = tmp_path / 'cam0' / 'broken.jpg'
+    bad.write_bytes(b'not a jpeg')
+    names.append(str(bad))
+    return tmp_path, sorted(names)
+
+
+def _strip(results):
+    return json.loads(json.dumps(sorted(results, key=lambda r: r['file'])))
+
+
+def test_orchestration_modes_give_identical_results(image_dir):
+    """reference md_tests.py:1251,1267,1283: queue / preprocess-queue / batched runs must equal the plain run"""
+    root, names = image_dir
+    plain = RDB.load_and_run_detector_batch('stub', str(root), detector=StubDetector(), quiet=True)
+    assert sorted(r['file'] for r in plain) == names
+    broken = [r for r in plain if r['file'].endswith('broken.jpg')][0]
+    assert broken == {'file': broken['file'], 'failure': run_detector.FAILURE_IMAGE_OPEN}
+    for kw in (dict(batch_size=4), dict(use_image_queue=True), dict(use_image_queue=True, batch_size=3),
+               dict(use_image_queue=True, batch_size=3, preprocess_on_image_queue=True, loader_workers=2)):
+        det = StubDetector()
+        got = RDB.load_and_run_detector_batch('stub', names, detector=det, quiet=True, **kw)
+        assert _strip(got) == _strip(plain), kw
+        if kw.get('batch_size', 1) > 1:
+            assert max(det.batches) <= kw['batch_size']
+
+
+def test_threshold_applied_after_batched_detector(image_dir):
+    root, names = image_dir
+    res = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), batch_size=4,
+                                          confidence_threshold=0.5, quiet=True)
+    for r in res:
+        if 'failure' not in r:
+            assert all(d['conf'] >= 0.5 for d in r['detections'])
+
+
+def test_batch_failure_marks_only_that_batch(image_dir):
+    root, names = image_dir
+    good = [n for n in names if not n.endswith('broken.jpg')]
+    det = StubDetector(fail_on={good[5]})
+    res = RDB.load_and_run_detector_batch('stub', good, detector=det, batch_size=4, quiet=True)
+    failed = [r['file'] for r in res if r.get('failure') == run_detector.FAILURE_INFER]
+    assert failed == good[4:8]
+    assert all('detections' in r for r in res if r['file'] not in failed)
+
+
+def test_checkpoint_resume_and_json_format(image_dir, tmp_path):
+    root, names = image_dir
+    ck = str(tmp_path / 'ck.json')
+    first = RDB.load_and_run_detector_batch('stub', names[:6], detector=StubDetector(), checkpoint_path=ck,
+                                            checkpoint_frequency=2, quiet=True)
+    restored = RDB.load_checkpoint(ck)
+    assert [r['file'] for r in restored] == [r['file'] for r in first]
+    det = StubDetector()
+    full = RDB.load_and_run_detector_batch('stub', names, detector=det, results=restored, quiet=True)
+    plain = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True)
+    assert _strip(full) == _strip(plain)
+    out = str(tmp_path / 'out' / 'results.json')
+    written = RDB.write_results_to_file(full, out, relative_path_base=str(root), detector_file='md_v5a.0.0.pt')
+    on_disk = json.load(open(out))
+    assert on_disk == json.loads(json.dumps(written))
+    assert on_disk['info']['format_version'] == '1.6'
+    assert on_disk['info']['detector_metadata']['megadetector_version'] == 'v5a.0.1'
+    assert on_disk['detection_categories'] == {'1': 'animal', '2': 'person', '3': 'vehicle'}
+    files = [im['file'] for im in on_disk['images']]
+    assert files == sorted(files) and not any(f.startswith('/') for f in files)
+    for im in on_disk['images']:
+        assert 'max_detection_conf' not in im
+        if 'failure' in im:
+            assert im['detections'] is None
+        else:
+            confs = [d['conf'] for d in im['detections']]
+            assert confs == sorted(confs, reverse=True)
+
+
+def test_sharding_is_balanced_and_merge_checks(image_dir):
+    root, names = image_dir
+    shards = RDB.shard_image_list(names, 8)
+    assert sorted(sum(shards, [])) == names
+    assert max(map(len, shards)) - min(map(len, shards)) <= 1
+    res = [RDB.load_and_run_detector_batch('stub', s, detector=StubDetector(), quiet=True) for s in shards]
+    merged = RDB.merge_shard_results(res, expected_files=names)
+    plain = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True)
+    assert _strip(merged) == _strip(plain)
+    with pytest.raises(ValueError, match='duplicate'):
+        RDB.merge_shard_results([res[0], res[0]])
+    with pytest.raises(ValueError, match='no result'):
+        RDB.merge_shard_results(res[:-1], expected_files=names)
+
+
+def test_model_name_resolution(monkeypatch, tmp_path):
+    assert run_detector.get_detector_version_from_filename('/x/md_v5a.0.0.pt') == 'v5a.0.1'
+    assert run_detector.get_detector_version_from_filename('whatever.pt') == 'unknown'
+    fake = tmp_path / 'md_v5a.0.0.pt'
+    fake.write_bytes(b'')
+    monkeypatch.setenv('MDV5A', str(fake))
+    assert run_detector.try_download_known_detector('MDV5A') == str(fake)
+    monkeypatch.delenv('MDV5A')
+    with pytest.raises(FileNotFoundError):
+        run_detector.try_download_known_detector('MDV5A')
+    assert run_detector.try_download_known_detector('/some/file.pt') == '/some/file.pt'
+    with pytest.raises(ValueError):
+        run_detector.load_detector('model.pb')
+
+
+# ---------------------------------------------------------------------------------------------
+# world_size-2 gloo run of the one-process-per-GPU path (no GPU needed: stub detector)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gloo_worker(rank, world, port, names, out_path):
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from megadetector_amd import sharded
+    from megadetector_amd import run_detector_batch as rdb
+    from test_batch_loop import StubDetector as Stub
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{}'.format(port), rank=rank, world_size=world)
+    mine = sharded.my_shard(names, rank, world)
+    res = rdb.load_and_run_detector_batch('stub', mine, detector=Stub(), quiet=True, batch_size=3)
+    dist.barrier()
+    slowest = sharded.max_over_ranks(1.0 + rank, dist)
+    merged = sharded.gather_results(res, dist, expected_files=names)
+    if rank == 0:
+        with open(out_path, 'w') as f:
+            json.dump({'merged': merged, 'slowest': slowest}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_run_matches_single_process(image_dir, tmp_path):
+    import torch.multiprocessing as mp
+    root, names = image_dir
+    out_path = str(tmp_path / 'merged.json')
+    mp.spawn(_gloo_worker, args=(2, _free_port(), names, out_path), nprocs=2, join=True)
+    got = json.load(open(out_path))
+    plain = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True, batch_size=3)
+    assert _strip(got['merged']) == _strip(plain)
+    assert got['slowest'] == 2.0
