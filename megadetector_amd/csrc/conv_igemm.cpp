@@ -85,7 +85,10 @@ constexpr int conv_waves_per_simd(int bm, int bn, int nw, int ns) {
     return w < 1 ? 1 : w;
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+// FP = 1: fragment prefetch -- the LDS reads of the next 32-deep half slab are issued before the
+// MFMAs of the current one (two register sets), so ds_read latency hides under the matrix pipe
+// instead of in front of it; needs NS >= 3 because the next slab must already have landed.
+template <int BM, int BN, int WM, int WN, int NS, int FP>
 __global__ void __launch_bounds__(WM * WN * 64, conv_waves_per_simd(BM, BN, WM * WN, NS))
 conv_igemm_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource
@@ -102,6 +105,7 @@ conv_igemm_kernel(const ConvArgs p) {
     static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
     static_assert(NS >= 2 && (NS - 2) * LPS < 64, "vmcnt is a 6-bit counter");
+    static_assert(!FP || NS >= 3, "fragment prefetch needs three LDS stages");
     // every wave issues exactly LPS loads per slab (uniform vmcnt bookkeeping); when BN/8 does
     // not divide by the wave count the surplus loads are out-of-range (zeros) and land in one
     // shared 1 KiB dump area behind the last stage
@@ -288,6 +292,24 @@ conv_igemm_kernel(const ConvArgs p) {
     };
 
     // ---- software pipeline over (tile, slab) steps ----------------------------------------
+    auto load_frags = [&](bf16x8 (&xf)[FM], bf16x8 (&wf)[FN], int slot, int kk) {
+        const lds_char* sbase = smem + slot * STAGE;
+        const int choff = frag_ch0 ^ (kk * 64);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+            xf[i] = *(const __attribute__((address_space(3))) bf16x8*)(sbase + a_frag_base + i * 2048 + choff);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            wf[j] = *(const __attribute__((address_space(3))) bf16x8*)(sbase + b_frag_base + j * 2048 + choff);
+    };
+    auto mfma_block = [&](const bf16x8 (&xf)[FM], const bf16x8 (&wf)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    };
+
     int issued = 0;
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
@@ -296,37 +318,53 @@ conv_igemm_kernel(const ConvArgs p) {
     int cur = 0;                 // ring slot of the slab being consumed
     int nxt = NS - 1;            // ring slot the next issued slab goes to
     int c_kt = 0, c_tile = first_tile;
-    for (int step = 0; step < total_steps; ++step) {
-        // this wave's loads of the current slab have landed; up to NS-2 younger slabs stay in flight
-        if (step + (NS - 2) < total_steps) wait_vmcnt<(NS - 2) * LPS>();
-        else wait_vmcnt<0>();    // tail: fewer slabs are outstanding than the steady-state count
-        __builtin_amdgcn_s_barrier();
-        if (issued < total_steps) { issue(nxt); ++issued; }
 
-        const lds_char* sbase = smem + cur * STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int choff = frag_ch0 ^ (kk * 64);
-            bf16x8 xf[FM], wf[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-                xf[i] = *(const __attribute__((address_space(3))) bf16x8*)(sbase + a_frag_base + i * 2048 + choff);
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                wf[j] = *(const __attribute__((address_space(3))) bf16x8*)(sbase + b_frag_base + j * 2048 + choff);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    if constexpr (FP) {
+        bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+        if (NS - 2 < total_steps) wait_vmcnt<(NS - 2) * LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        load_frags(xa, wa, 0, 0);
+        for (int step = 0; step < total_steps; ++step) {
+            load_frags(xb, wb, cur, 1);              // second half of this slab ...
+            mfma_block(xa, wa);                      // ... while the first half multiplies
+            // the next slab must have landed (this wave's part), then everyone's
+            if (step + (NS - 2) < total_steps) wait_vmcnt<(NS - 3) * LPS>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (issued < total_steps) { issue(nxt); ++issued; }
+            const int nslot = (cur + 1 == NS) ? 0 : cur + 1;
+            if (step + 1 < total_steps) load_frags(xa, wa, nslot, 0);
+            mfma_block(xb, wb);
+            if (++c_kt == KT) {
+                epilogue(c_tile);
+                c_kt = 0;
+                c_tile += tile_step;
+            }
+            cur = nslot;
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
-        if (++c_kt == KT) {      // tile finished: write it out while the next tile's slabs stream in
-            epilogue(c_tile);
-            c_kt = 0;
-            c_tile += tile_step;
+    } else {
+        for (int step = 0; step < total_steps; ++step) {
+            // this wave's loads of the current slab have landed; up to NS-2 younger slabs stay in flight
+            if (step + (NS - 2) < total_steps) wait_vmcnt<(NS - 2) * LPS>();
+            else wait_vmcnt<0>();    // tail: fewer slabs are outstanding than the steady-state count
+            __builtin_amdgcn_s_barrier();
+            if (issued < total_steps) { issue(nxt); ++issued; }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 xf[FM], wf[FN];
+                load_frags(xf, wf, cur, kk);
+                mfma_block(xf, wf);
+            }
+            if (++c_kt == KT) {      // tile finished: write it out while the next tile's slabs stream in
+                epilogue(c_tile);
+                c_kt = 0;
+                c_tile += tile_step;
+            }
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
-        cur = (cur + 1 == NS) ? 0 : cur + 1;
-        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -334,41 +372,41 @@ conv_igemm_kernel(const ConvArgs p) {
 // ---------------------------------------------------------------------------------------
 // configuration table
 // ---------------------------------------------------------------------------------------
-// id, BM, BN, waves along M, waves along N, LDS stages
-#define MDHIP_CONV_CFGS(X)  \
-    X(0, 256, 160, 4, 2, 2) \
-    X(1, 128, 160, 2, 2, 2) \
-    X(2, 256, 80, 4, 1, 2)  \
-    X(3, 128, 80, 4, 1, 2)  \
-    X(4, 256, 32, 4, 1, 2)  \
-    X(5, 128, 64, 2, 2, 2)  \
-    X(6, 128, 128, 2, 2, 2) \
-    X(7, 256, 128, 4, 2, 2) \
-    X(8, 128, 320, 2, 4, 2) \
-    X(9, 64, 160, 1, 2, 2)  \
-    X(10, 64, 64, 1, 2, 2)  \
-    X(11, 256, 64, 4, 1, 2) \
-    X(12, 256, 160, 4, 2, 3) \
-    X(13, 128, 160, 2, 2, 3) \
-    X(14, 128, 160, 2, 2, 4) \
-    X(15, 128, 80, 4, 1, 3)  \
-    X(16, 128, 80, 4, 1, 4)  \
-    X(17, 256, 80, 4, 1, 3)  \
-    X(18, 256, 128, 4, 2, 3) \
-    X(19, 128, 128, 2, 2, 3) \
-    X(20, 128, 128, 2, 2, 4) \
-    X(21, 64, 160, 1, 2, 4)  \
-    X(22, 128, 64, 2, 2, 4)  \
-    X(23, 256, 32, 4, 1, 4)  \
-    X(24, 256, 320, 2, 4, 2) \
-    X(25, 256, 160, 2, 2, 2) \
-    X(26, 256, 320, 4, 4, 2) \
-    X(27, 256, 160, 2, 2, 3)
+// id, BM, BN, waves along M, waves along N, LDS stages, fragment prefetch
+#define MDHIP_CONV_CFGS(X)     \
+    X(0, 256, 160, 4, 2, 2, 0) \
+    X(1, 128, 160, 2, 2, 2, 0) \
+    X(2, 256, 80, 4, 1, 2, 0)  \
+    X(3, 128, 80, 4, 1, 2, 0)  \
+    X(4, 256, 32, 4, 1, 2, 0)  \
+    X(5, 128, 64, 2, 2, 2, 0)  \
+    X(6, 128, 128, 2, 2, 2, 0) \
+    X(7, 256, 128, 4, 2, 2, 0) \
+    X(8, 128, 320, 2, 4, 2, 0) \
+    X(9, 64, 160, 1, 2, 2, 0)  \
+    X(10, 64, 64, 1, 2, 2, 0)  \
+    X(11, 256, 64, 4, 1, 2, 0) \
+    X(12, 256, 160, 4, 2, 3, 0) \
+    X(13, 128, 160, 2, 2, 3, 1) \
+    X(14, 256, 160, 4, 2, 3, 1) \
+    X(15, 128, 80, 4, 1, 3, 0)  \
+    X(16, 128, 80, 4, 1, 3, 1)  \
+    X(17, 256, 80, 4, 1, 3, 1)  \
+    X(18, 256, 128, 4, 2, 3, 0) \
+    X(19, 128, 128, 2, 2, 3, 1) \
+    X(20, 256, 128, 4, 2, 3, 1) \
+    X(21, 64, 160, 1, 2, 4, 0)  \
+    X(22, 128, 64, 2, 2, 4, 1)  \
+    X(23, 256, 32, 4, 1, 4, 0)  \
+    X(24, 256, 320, 2, 4, 2, 0) \
+    X(25, 128, 80, 2, 1, 3, 1)  \
+    X(26, 256, 320, 4, 4, 2, 0) \
+    X(27, 128, 160, 4, 2, 3, 1)
 
 static const ConvCfg g_cfgs[] = {
-#define X(id, bm, bn, wm, wn, ns)                                                                   \
+#define X(id, bm, bn, wm, wn, ns, fp)                                                                 \
     {bm, bn, (wm) * (wn) * 64, (size_t)conv_lds_bytes(bm, bn, ns),                                  \
-     conv_blocks_per_cu(bm, bn, (wm) * (wn), ns), #bm "x" #bn "/" #wm "x" #wn "/s" #ns},
+     conv_blocks_per_cu(bm, bn, (wm) * (wn), ns), #bm "x" #bn "/" #wm "x" #wn "/s" #ns "/p" #fp},
     MDHIP_CONV_CFGS(X)
 #undef X
 };
@@ -378,9 +416,9 @@ const ConvCfg& conv_cfg(int i) { return g_cfgs[i]; }
 
 hipError_t conv_init() {
     hipError_t e = hipSuccess;
-#define X(id, bm, bn, wm, wn, ns)                                                                  \
+#define X(id, bm, bn, wm, wn, ns, fp)                                                                \
     if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<bm, bn, wm, wn, ns>,                \
+        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<bm, bn, wm, wn, ns, fp>,                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs[id].lds_bytes);
     MDHIP_CONV_CFGS(X)
 #undef X
@@ -399,9 +437,9 @@ hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     p.m_streams = std::max(1, std::min(p.tiles_per_xcd, (32 * c.blocks_per_cu) / p.tiles_n));
     const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
     switch (cfg) {
-#define X(id, bm, bn, wm, wn, ns)                                                                 \
+#define X(id, bm, bn, wm, wn, ns, fp)                                                               \
     case id:                                                                                      \
-        hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, ns>), grid, dim3((wm) * (wn) * 64), \
+        hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, ns, fp>), grid, dim3((wm) * (wn) * 64), \
                            c.lds_bytes, s, p);                                                    \
         break;
         MDHIP_CONV_CFGS(X)
