@@ -23,7 +23,7 @@ if [ "$STAGE" = "all" ] || [ "$STAGE" = "bench" ]; then
   echo "bench exit $?" >> gpurun_out/bench.log
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "prof" ]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r1 -- \
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r1 -- \
      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/rocprof.log" 2>&1)
   find gpurun_out/prof -name "*stats*" | head >> gpurun_out/rocprof.log
   # keep only the small summaries
