@@ -411,8 +411,11 @@ static const ConvCfg g_cfgs[] = {
 #undef X
 };
 
-int conv_num_cfgs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
-const ConvCfg& conv_cfg(int i) { return g_cfgs[i]; }
+// configuration ids: [0, kNumV1) = this file's kernel, [kNumV1, ...) = conv_v2.cpp
+constexpr int kNumV1 = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
+int conv_num_v1_cfgs() { return kNumV1; }
+int conv_num_cfgs() { return kNumV1 + conv2_num_cfgs(); }
+const ConvCfg& conv_cfg(int i) { return i < kNumV1 ? g_cfgs[i] : conv2_cfg(i - kNumV1); }
 
 hipError_t conv_init() {
     hipError_t e = hipSuccess;
@@ -422,11 +425,14 @@ hipError_t conv_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs[id].lds_bytes);
     MDHIP_CONV_CFGS(X)
 #undef X
+    if (e == hipSuccess) e = conv2_init();
     return e;
 }
 
 hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
-    if (cfg < 0 || cfg >= conv_num_cfgs()) return hipErrorInvalidValue;
+    // negative ids -1, -2, ... address conv_v2.cpp's instrumented variants (developer tools only)
+    if (cfg >= conv_num_cfgs()) return hipErrorInvalidValue;
+    if (cfg >= kNumV1 || cfg < 0) return conv2_launch(cfg < 0 ? conv2_num_cfgs() - 1 - cfg : cfg - kNumV1, a, s);
     const ConvCfg& c = g_cfgs[cfg];
     ConvArgs p = a;
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;

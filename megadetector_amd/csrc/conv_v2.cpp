@@ -1,0 +1,501 @@
+// Implicit-GEMM convolution, second generation main loop (gfx950 / MI355X).
+//
+// Same GEMM view, data layout, LDS image and epilogue contract as conv_igemm.cpp (read its header
+// first); what changes is the schedule, driven by two measurements on MI355X (profiles/r1a_*):
+//   * removing the LDS fragment reads from the v1 loop gains 4 %, removing the HBM/L2 -> LDS loads
+//     gains 29 %: the matrix pipe idles while a wave *issues* its buffer_load...lds burst
+//     (~60 cycles of issue per 1 KiB piece) and its address arithmetic in front of the MFMAs;
+//   * 128-row tiles leave 6.25 tiles per workgroup slot on the 80x80 / 160x160 feature maps
+//     (7 rounds for 6.25 rounds of work); 160-row tiles divide them exactly.
+// So here every wave's instruction stream is a uniform mix: the step over one 64-deep K slab is
+// split at the workgroup barrier into two halves of FM*FN MFMAs each, fragments are double-buffered
+// in registers, and the LDS-DMA pieces of slab s+2, the fragment reads of slab s+1 and the MFMAs of
+// slab s are interleaved instruction by instruction.  Two independent workgroups share a CU, so the
+// partner wave on a SIMD always has matrix work ready while this wave issues memory operations.
+//
+//   step s (cur = s & 1):                                    LDS stage cur holds slab s
+//     read  Y  <- stage cur, k 32..63                         } interleaved
+//     mfma  X  (k 0..31 of slab s)                            }
+//     s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier                 slab s+1 landed everywhere; stage cur free
+//     DMA   slab s+2 -> stage cur                             }
+//     read  X' <- stage cur^1, k 0..31 of slab s+1            } interleaved
+//     mfma  Y  (k 32..63 of slab s)                           }
+//     advance the loader (branch-free inside a tile) ; epilogue when the tile's last slab is done
+//
+// Bias comes in through the scalar cache in the epilogue (no LDS, no vector registers), so a
+// workgroup's LDS is exactly the two stages: 160x160 tiles use 2 x 80 KiB = the whole CU.
+
+#include <algorithm>
+#include <type_traits>
+
+#include "mdhip_internal.h"
+
+namespace mdhip {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records: the lane reads zeros
+constexpr int kNumRecords = 0x7fffffff;
+
+__device__ __forceinline__ float silu_f32(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return *(const uint32_t*)&r;
+}
+
+constexpr int v2_lds_bytes(int bm, int bn) { return 2 * (bm + bn) * 128; }
+constexpr int v2_blocks_per_cu(int bm, int bn, int nw) {
+    int b = 163840 / v2_lds_bytes(bm, bn);
+    if (b > 32 / nw) b = 32 / nw;
+    if (b > 2) b = 2;
+    return b < 1 ? 1 : b;
+}
+constexpr int v2_waves_per_simd(int bm, int bn, int nw) {
+    int w = v2_blocks_per_cu(bm, bn, nw) * nw / 4;
+    return w < 1 ? 1 : w;
+}
+
+}  // namespace
+
+#define MDHIP_DMA16(rsrc, lptr, voff, soff) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr), 16, (voff), (soff), 0, 0)
+
+// PROF = 1: timing-only instrumentation (s_memtime at the phase boundaries of every step, summed per
+// wave and written to p.dbg); used by tools/convbench.cpp, never by the product path
+template <int BM, int BN, int WM, int WN, int PROF = 0>
+__global__ void __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BM, BN, WM * WN))
+conv_v2_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int B_INSTR = BN / 8;                       // 1 KiB pieces (8 rows x 128 B) of the weight tile
+    constexpr int A_PER = BM / 8 / NW, B_PER = (B_INSTR + NW - 1) / NW;
+    constexpr bool B_RAGGED = (B_INSTR % NW) != 0;        // the last piece exists only on the first waves
+    static_assert((BM / 8) % NW == 0, "the activation tile must split evenly over the waves");
+    static_assert(TM % 16 == 0 && TN % 16 == 0 && TM % 8 == 0, "wave tile must be a multiple of 16x16");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lds_char* const smem = (lds_char*)smem_generic;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- persistent streams (see conv_igemm.cpp): block b runs on XCD b % 8 ---------------------
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_n = slot % p.tiles_n;
+    const int ms = slot / p.tiles_n;
+    const int xcd_first = xcd * p.tiles_per_xcd;
+    const int xcd_tiles = min(p.tiles_per_xcd, p.tiles_m - xcd_first);
+    const int my_tiles = (xcd_tiles > ms) ? (xcd_tiles - ms + p.m_streams - 1) / p.m_streams : 0;
+    if (my_tiles <= 0) return;
+    const int first_tile = xcd_first + ms;
+    const int tile_step = p.m_streams;
+    const int last_tile = first_tile + (my_tiles - 1) * tile_step;
+    const int n0 = tile_n * BN;
+    const int KT = p.k_pad >> 6;
+    const int total_steps = my_tiles * KT;
+
+    // ---- weight side ----------------------------------------------------------------------------
+    const int lr = lane >> 3;
+    const int jj = (lane & 7) ^ lr;        // swizzled source chunk inside the 128-byte K slab
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.wgt + (size_t)n0 * p.k_pad), 0, kNumRecords, 0x00020000);
+    unsigned b_off[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int row = (i * NW + wave) * 8 + lr;
+        b_off[i] = (n0 + row < p.n_rows) ? (unsigned)(row * p.k_pad + jj * 8) * 2u : kOOB;
+    }
+
+    // ---- activation side: loader state ----------------------------------------------------------
+    __amdgpu_buffer_rsrc_t a_rsrc = b_rsrc;
+    unsigned a_off[A_PER];
+    uint32_t a_mask[A_PER];
+    // position of this lane's 16-byte chunk inside K (valid for C8 >= 8: at most one tap wrap per slab)
+    int c8 = 0, ts = 0;
+    uint32_t tapbit = 1;
+    unsigned tapoff = 0;
+    int l_kt = 0, l_tile = first_tile;
+    bool l_live = true;                     // false once the stream has no more slabs to load
+    const int kh = p.ntaps / p.kw;
+    const unsigned wrap_c = (unsigned)(p.ld_in * 2 - p.C8 * 16);        // next tap, same row
+    const unsigned wrap_r = (unsigned)((p.W - p.kw) * p.ld_in * 2);     // first tap of the next kernel row
+
+    auto init_tile = [&](int tile_m) {
+        const int m0 = tile_m * BM;
+        const int b0 = m0 / p.HoWo;
+        const int rem0 = m0 - b0 * p.HoWo;
+        const int oy0 = rem0 / p.Wo;
+        const int ox0 = rem0 - oy0 * p.Wo;
+        const long long base_px = (long long)(b0 * p.H + oy0 * p.stride - p.pad) * p.W + (ox0 * p.stride - p.pad);
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + base_px * p.ld_in), 0, kNumRecords, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int row = (i * NW + wave) * 8 + lr;
+            const int m = m0 + row;
+            uint32_t mask = 0;
+            unsigned off = 0;
+            if (m < p.M) {
+                const int b = m / p.HoWo;
+                const int rem = m - b * p.HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad;
+                const int ix0 = ox * p.stride - p.pad;
+                const long long px = (long long)(b * p.H + iy0) * p.W + ix0;
+                off = (unsigned)((px - base_px) * p.ld_in * 2);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        if (r < kh && s < p.kw && (unsigned)(iy0 + r) < (unsigned)p.H &&
+                            (unsigned)(ix0 + s) < (unsigned)p.W)
+                            mask |= 1u << (r * p.kw + s);
+            }
+            a_off[i] = off;
+            a_mask[i] = mask;
+        }
+        c8 = jj; ts = 0; tapbit = 1; tapoff = (unsigned)jj * 16u;
+    };
+
+    // the loader moves on by one slab (branch-free inside a tile)
+    auto advance = [&]() {
+        if (++l_kt == KT) {
+            l_kt = 0;
+            if (l_tile == last_tile) {
+                l_live = false;
+#pragma unroll
+                for (int i = 0; i < A_PER; ++i) a_mask[i] = 0;
+            } else {
+                l_tile += tile_step;
+                init_tile(l_tile);
+            }
+        } else {
+            c8 += 8;
+            tapoff += 128u;
+            const bool w = c8 >= p.C8;
+            c8 = w ? c8 - p.C8 : c8;
+            tapoff += w ? wrap_c : 0u;
+            tapbit = w ? tapbit << 1 : tapbit;
+            ts += w ? 1 : 0;
+            const bool w2 = ts == p.kw;
+            ts = w2 ? 0 : ts;
+            tapoff += w2 ? wrap_r : 0u;
+        }
+    };
+
+    // one LDS-DMA piece of the loader's current slab into stage `buf`
+    auto dma_a = [&](int buf, int i) {
+        if constexpr ((PROF & 16) != 0) return;
+        const unsigned voff = (a_mask[i] & tapbit) ? a_off[i] + tapoff : kOOB;
+        MDHIP_DMA16(a_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, voff, 0);
+    };
+    auto dma_b = [&](int buf, int i) {
+        if constexpr ((PROF & 16) != 0) return;
+        if (B_RAGGED && i == B_PER - 1 && wave >= B_INSTR % NW) return;     // wave-uniform
+        const unsigned voff = l_live ? b_off[i] : kOOB;
+        MDHIP_DMA16(b_rsrc, smem + buf * STAGE + A_BYTES + (i * NW + wave) * 1024, voff, l_kt * 128);
+    };
+
+    // ---- fragment reads ---------------------------------------------------------------------------
+    const int frag_row_off = (lane & 15) * 128;
+    const int frag_ch0 = (((lane >> 4) ^ (lane & 7)) * 16);      // k 0..31 ; k 32..63 is ^ 64
+    const int a_frag_base = (wm * TM) * 128 + frag_row_off;
+    const int b_frag_base = A_BYTES + (wn * TN) * 128 + frag_row_off;
+    auto read_x = [&](int buf, int kk, int i) -> bf16x8 {
+        if constexpr ((PROF & 32) != 0) { bf16x8 z = {(short)(lane + i), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(z)); return z; }
+        return *(const __attribute__((address_space(3))) bf16x8*)(smem + buf * STAGE + a_frag_base + i * 2048 +
+                                                                 (frag_ch0 ^ (kk * 64)));
+    };
+    auto read_w = [&](int buf, int kk, int j) -> bf16x8 {
+        if constexpr ((PROF & 32) != 0) { bf16x8 z = {(short)(lane + j), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(z)); return z; }
+        return *(const __attribute__((address_space(3))) bf16x8*)(smem + buf * STAGE + b_frag_base + j * 2048 +
+                                                                 (frag_ch0 ^ (kk * 64)));
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- epilogue: lane holds channels n..n+3 of pixel m ----------------------------------------
+    // Specialised on (residual, fp32 output) so that the common path has no wait between stores: a
+    // vmcnt wait in front of every store would serialise them on the memory round trip (measured:
+    // 36k cycles per 160x160 tile, as long as the tile's MFMAs).  Residual rows are fetched one
+    // fragment column ahead of their use, so waiting for them never waits for a store.
+    const int q4 = lane >> 4;
+    auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t) {
+        constexpr bool HAS_RES = decltype(has_res_t)::value;
+        constexpr bool OUT_F32 = decltype(out_f32_t)::value;
+        const int m0 = tile_m * BM + wm * TM + (lane & 15);
+        const int nbase = n0 + wn * TN + q4 * 4;
+        uint2 rbuf[2][FM];
+        auto fetch_res = [&](int j, uint2 (&r)[FM]) {
+            // branch-free (clamped) addresses: a load under a divergent branch would make the
+            // compiler fall back from counted vmcnt waits to vmcnt(0), which also waits for stores
+            const int n = min(nbase + j * 16, p.N - 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = min(m0 + i * 16, p.M - 1);
+                r[i] = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
+            }
+        };
+        if constexpr (HAS_RES) fetch_res(0, rbuf[0]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if constexpr (HAS_RES) {
+                if (j + 1 < FN) fetch_res(j + 1, rbuf[(j + 1) & 1]);
+            }
+            const int nb = n0 + wn * TN + j * 16;                // wave-uniform: bias comes through s_load
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (nb < p.n_rows) {
+                // 16 biases of this fragment column through the scalar cache (explicit s_load: the
+                // compiler will not use the scalar path for memory it cannot prove read-only, and a
+                // vector load here would put a vmcnt(0) in front of the stores)
+                f32x16 b16;
+                const unsigned long long ba = (unsigned long long)(p.bias + nb);
+                const unsigned long long bs =
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)ba);
+                asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b16) : "s"(bs) : "memory");
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    bv[r] = q4 == 0 ? b16[r] : (q4 == 1 ? b16[4 + r] : (q4 == 2 ? b16[8 + r] : b16[12 + r]));
+            }
+            const int n = nbase + j * 16;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + i * 16;
+                float v0 = acc[i][j][0] + bv[0];
+                float v1 = acc[i][j][1] + bv[1];
+                float v2 = acc[i][j][2] + bv[2];
+                float v3 = acc[i][j][3] + bv[3];
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((PROF & 4) == 0 && p.act) {
+                    v0 = silu_f32(v0); v1 = silu_f32(v1); v2 = silu_f32(v2); v3 = silu_f32(v3);
+                }
+                if constexpr (HAS_RES) {
+                    const uint2 rv = rbuf[j & 1][i];
+                    v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff));
+                    v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
+                    v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff));
+                    v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+                }
+                if (m >= p.M || n >= p.N) continue;
+                if constexpr ((PROF & 2) != 0) {
+                    asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
+                } else if constexpr (OUT_F32) {
+                    *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v0, v1, v2, v3);
+                } else {
+                    uint2 o;
+                    o.x = pack2_bf16(v0, v1);
+                    o.y = pack2_bf16(v2, v3);
+                    *(uint2*)((uint16_t*)p.out + (size_t)m * p.ld_out + n) = o;
+                }
+            }
+        }
+    };
+    auto epilogue = [&](int tile_m) {
+        if constexpr ((PROF & 8) != 0) __builtin_amdgcn_s_setprio(3);
+        if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{});
+        else if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{});
+        else epilogue_t(tile_m, std::false_type{}, std::false_type{});
+        if constexpr ((PROF & 8) != 0) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: slabs 0 and 1 in flight, fragments X of slab 0 in registers ---------------------
+    init_tile(first_tile);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) dma_a(0, i);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) dma_b(0, i);
+    advance();
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) dma_a(1, i);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) dma_b(1, i);
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xa[i] = read_x(0, 0, i);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wa[j] = read_w(0, 0, j);
+
+    int c_kt = 0, c_tile = first_tile;
+    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    auto stamp = [&](int k) {
+        if constexpr ((PROF & 1) != 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            t_acc[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if constexpr ((PROF & 1) != 0) t_prev = __builtin_amdgcn_s_memtime();
+    for (int step = 0; step < total_steps; ++step) {
+        const int cur = step & 1;
+        // ---- first half: k 0..31 of slab `step`, while its k 32..63 fragments are read ----------
+#pragma unroll
+        for (int i = 0; i < FM; ++i) xb[i] = read_x(cur, 1, i);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wb[j] = read_w(cur, 1, j);
+        if constexpr ((PROF & 64) == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+
+        stamp(0);
+        // slab step+1 has landed (this wave's pieces), stage `cur` is fully in registers
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(1);
+        __builtin_amdgcn_s_barrier();
+        stamp(2);
+
+        // ---- second half: DMA of slab step+2 into stage cur, X fragments of slab step+1,
+        //      MFMAs on k 32..63 of slab step -------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) dma_a(cur, i);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) dma_b(cur, i);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) xa[i] = read_x(cur ^ 1, 0, i);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wa[j] = read_w(cur ^ 1, 0, j);
+        if constexpr ((PROF & 64) == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+        }
+
+        stamp(3);
+        advance();
+        stamp(4);
+        if (++c_kt == KT) {
+            epilogue(c_tile);
+            c_kt = 0;
+            c_tile += tile_step;
+        }
+        stamp(5);
+    }
+    if constexpr ((PROF & 1) != 0) {
+        if (lane == 0 && p.dbg) {
+            unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+            for (int k = 0; k < 6; ++k) d[k] = t_acc[k];
+            d[6] = (unsigned long long)total_steps;
+            d[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) ;   // HW_REG_XCC_ID
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------
+// configuration table
+// ---------------------------------------------------------------------------------------
+// id (local), BM, BN, waves along M, waves along N
+#define MDHIP_CONV2_CFGS(X) \
+    X(0, 160, 160, 2, 2)    \
+    X(1, 128, 160, 2, 2)    \
+    X(2, 160, 80, 2, 1)     \
+    X(3, 128, 80, 4, 1)     \
+    X(4, 96, 160, 2, 2)     \
+    X(5, 64, 160, 1, 2)     \
+    X(6, 192, 160, 4, 2)    \
+    X(7, 256, 160, 4, 2)    \
+    X(8, 320, 160, 4, 2)
+// id, BM, BN, WM, WN, PROF bits (1 = s_memtime stamps, 2 = no stores, 4 = no SiLU)
+#define MDHIP_CONV2_PROF(X) \
+    X(9, 160, 160, 2, 2, 1)  \
+    X(10, 320, 160, 4, 2, 1) \
+    X(11, 160, 160, 2, 2, 54) \
+    X(12, 160, 160, 2, 2, 102) \
+    X(13, 320, 160, 4, 2, 102) \
+    X(14, 320, 160, 4, 2, 38)
+
+static const ConvCfg g_cfgs2[] = {
+#define X(id, bm, bn, wm, wn)                                                                        \
+    {bm, bn, (wm) * (wn) * 64, (size_t)v2_lds_bytes(bm, bn), v2_blocks_per_cu(bm, bn, (wm) * (wn)), \
+     "v2:" #bm "x" #bn "/" #wm "x" #wn},
+    MDHIP_CONV2_CFGS(X)
+#undef X
+#define X(id, bm, bn, wm, wn, prof)                                                                  \
+    {bm, bn, (wm) * (wn) * 64, (size_t)v2_lds_bytes(bm, bn), v2_blocks_per_cu(bm, bn, (wm) * (wn)), \
+     "v2prof" #prof ":" #bm "x" #bn "/" #wm "x" #wn},
+    MDHIP_CONV2_PROF(X)
+#undef X
+};
+constexpr int kNumProf = 6;    // trailing instrumented entries: reachable through conv2_launch only
+
+int conv2_num_cfgs() { return (int)(sizeof(g_cfgs2) / sizeof(g_cfgs2[0])) - kNumProf; }
+const ConvCfg& conv2_cfg(int i) { return g_cfgs2[i]; }
+
+hipError_t conv2_init() {
+    hipError_t e = hipSuccess;
+#define X(id, bm, bn, wm, wn)                                                                        \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
+    MDHIP_CONV2_CFGS(X)
+#undef X
+#define X(id, bm, bn, wm, wn, prof)                                                                  \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, prof>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
+    MDHIP_CONV2_PROF(X)
+#undef X
+    return e;
+}
+
+bool conv2_supports(const ConvArgs& a) {
+    // the branch-free K walk needs at least one whole slab per tap; the epilogue stores 4 channels
+    return a.C8 >= 8 && a.kw <= 3 && a.ntaps <= 9 && (a.k_pad % 64) == 0;
+}
+
+hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
+    if (cfg < 0 || cfg >= conv2_num_cfgs() + kNumProf || !conv2_supports(a)) return hipErrorInvalidValue;
+    const ConvCfg& c = g_cfgs2[cfg];
+    ConvArgs p = a;
+    p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;
+    p.tiles_m = (a.M + c.bm - 1) / c.bm;
+    p.tiles_per_xcd = (p.tiles_m + 7) / 8;
+    p.m_streams = std::max(1, std::min(p.tiles_per_xcd, (32 * c.blocks_per_cu) / p.tiles_n));
+    const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
+    switch (cfg) {
+#define X(id, bm, bn, wm, wn)                                                                        \
+    case id:                                                                                       \
+        hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        break;
+        MDHIP_CONV2_CFGS(X)
+#undef X
+#define X(id, bm, bn, wm, wn, prof)                                                                  \
+    case id:                                                                                       \
+        hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, prof>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        break;
+        MDHIP_CONV2_PROF(X)
+#undef X
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mdhip

@@ -503,7 +503,7 @@ int choose_cfg(int M, int n_rows) {
     static_assert(sizeof(quality) / sizeof(quality[0]) == 28, "one prior per tile configuration");
     int best = 0;
     float best_score = -1.f;
-    for (int i = 0; i < conv_num_cfgs(); ++i) {
+    for (int i = 0; i < conv_num_v1_cfgs(); ++i) {
         const ConvCfg& c = conv_cfg(i);
         const int tn = (n_rows + c.bn - 1) / c.bn, tm = (M + c.bm - 1) / c.bm;
         const float useful = ((float)n_rows / (tn * c.bn)) * ((float)M / ((float)tm * c.bm));
@@ -549,6 +549,7 @@ void fill_conv_args(mdhip_ctx* ctx, Op& op, int n, int h, int w, ConvArgs& a) {
     a.res = op.has_res ? (const uint16_t*)(ctx->arena + op.res.off) : nullptr;
     a.ld_res = op.has_res ? op.res.ld : 0;
     a.tiles_n = 1;
+    a.dbg = nullptr;
     op.gm = a.M;
     op.gn = pc.c_out;
     op.gk = pc.k_real;

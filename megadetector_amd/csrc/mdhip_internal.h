@@ -44,6 +44,7 @@ struct ConvArgs {
     int act;                // 1 = SiLU
     int out_f32;            // 1 = fp32 output, no rounding (Detect logits)
     int tiles_n, tiles_m, tiles_per_xcd, m_streams;   // filled by conv_launch
+    void* dbg;              // instrumentation output of the profiling variants (tools/convbench.cpp), else nullptr
 };
 
 struct ConvCfg {
@@ -58,6 +59,13 @@ const ConvCfg& conv_cfg(int i);
 // returns hipSuccess or the launch error
 hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s);
 hipError_t conv_init();   // one-off: raise dynamic-LDS limits
+int conv_num_v1_cfgs();   // ids below this run conv_igemm.cpp's kernel (every shape); the rest conv_v2.cpp's
+// second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
+int conv2_num_cfgs();
+const ConvCfg& conv2_cfg(int i);
+bool conv2_supports(const ConvArgs& a);
+hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s);
+hipError_t conv2_init();
 
 // ---------------------------------------------------------------------------------------
 // memory-bound helpers (misc_kernels.cpp)

@@ -1,0 +1,212 @@
+// Developer micro-benchmark for the implicit-GEMM conv kernels (not part of the product):
+// runs one conv shape with a list of tile configurations on random bf16 data, checks the
+// result against a naive GPU reference and prints ms / TFLOP/s.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/convbench.cpp megadetector_amd/csrc/conv_igemm.o -o gpurun_out/convbench
+//   ./convbench <shape> <iters> <cfg> [<cfg> ...]
+// shapes:  name  batch H W C_in C_out k stride   (see table below)
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../megadetector_amd/csrc/mdhip_internal.h"
+
+using namespace mdhip;
+
+#define CK(x)                                                                         \
+    do {                                                                              \
+        hipError_t e = (x);                                                           \
+        if (e != hipSuccess) {                                                        \
+            fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+struct Shape { const char* name; int b, h, w, cin, cout, k, s; bool res; };
+static const Shape kShapes[] = {
+    {"l26_3x3", 32, 80, 80, 320, 320, 3, 1, false},     // M 204800 N 320 K 2880  (x20, 20% of the net)
+    {"l6_3x3r", 32, 80, 80, 320, 320, 3, 1, true},      // same with residual (backbone)
+    {"l23_3x3", 32, 160, 160, 160, 160, 3, 1, false},   // M 819200 N 160 K 1440
+    {"l2_3x3", 32, 320, 320, 80, 80, 3, 1, true},       // M 3276800 N 80 K 720
+    {"l29_3x3", 32, 40, 40, 480, 480, 3, 1, false},     // M 51200 N 480 K 4320
+    {"l32_3x3", 32, 20, 20, 640, 640, 3, 1, false},     // M 12800 N 640 K 5760
+    {"l26_1x1", 32, 80, 80, 320, 320, 1, 1, false},     // M 204800 N 320 K 320
+    {"l23_1x1", 32, 160, 160, 160, 160, 1, 1, false},
+    {"l2_1x1", 32, 320, 320, 80, 80, 1, 1, false},
+    {"l26_cv3", 32, 80, 80, 640, 640, 1, 1, false},
+    {"l2_cv3", 32, 320, 320, 160, 160, 1, 1, false},
+    {"l1_s2", 32, 640, 640, 80, 160, 3, 2, false},      // M 3276800 N 160 K 720
+    {"l3_s2", 32, 320, 320, 160, 320, 3, 2, false},
+    {"l5_s2", 32, 160, 160, 320, 640, 3, 2, false},
+    {"small", 2, 24, 40, 64, 96, 3, 1, true},
+    {"small1", 2, 24, 40, 64, 96, 1, 1, false},
+    {"smalls2", 2, 24, 40, 64, 96, 3, 2, false},
+};
+
+__global__ void ref_conv(const uint16_t* in, const uint16_t* wgt, const float* bias, const uint16_t* res,
+                         uint16_t* out, int B, int H, int W, int C, int Ho, int Wo, int N, int k, int s,
+                         int pad, int k_pad, int cin_pad) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * Ho * Wo * N;
+    if (t >= total) return;
+    const int n = (int)(t % N);
+    const long long m = t / N;
+    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
+    float acc = 0.f;
+    for (int r = 0; r < k; ++r)
+        for (int q = 0; q < k; ++q) {
+            const int iy = oy * s - pad + r, ix = ox * s - pad + q;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+            const uint16_t* ip = in + ((size_t)(b * H + iy) * W + ix) * C;
+            const uint16_t* wp = wgt + (size_t)n * k_pad + (r * k + q) * cin_pad;
+            for (int c = 0; c < C; ++c) acc += bf16_to_f32(ip[c]) * bf16_to_f32(wp[c]);
+        }
+    float v = acc + bias[n];
+    v = v / (1.0f + expf(-v));
+    if (res) v += bf16_to_f32(res[(size_t)m * N + n]);
+    out[(size_t)m * N + n] = f32_to_bf16(v);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: convbench <shape> <iters> <cfg>...   (cfg -1 = all)\n");
+        return 2;
+    }
+    const Shape* sh = nullptr;
+    for (const Shape& s : kShapes)
+        if (!strcmp(s.name, argv[1])) sh = &s;
+    if (!sh) { fprintf(stderr, "unknown shape %s\n", argv[1]); return 2; }
+    const int iters = atoi(argv[2]);
+    std::vector<int> cfgs;
+    for (int i = 3; i < argc; ++i) {
+        if (!strcmp(argv[i], "all")) { for (int j = 0; j < conv_num_cfgs(); ++j) cfgs.push_back(j); continue; }
+        if (argv[i][0] == 'p') { cfgs.push_back(-1 - atoi(argv[i] + 1)); continue; }   // p0, p1: instrumented v2 variants
+        cfgs.push_back(atoi(argv[i]));
+    }
+    CK(conv_init());
+    const int pad = sh->k / 2;
+    const int Ho = sh->h / sh->s, Wo = sh->w / sh->s;
+    const long long M = (long long)sh->b * Ho * Wo;
+    const int cin_pad = (sh->cin + 7) / 8 * 8;
+    const int k_real = sh->k * sh->k * sh->cin;
+    const int k_pad = (sh->k * sh->k * cin_pad + 63) / 64 * 64;
+    const int n_rows = (sh->cout + 15) / 16 * 16;
+    const size_t in_elems = (size_t)sh->b * sh->h * sh->w * sh->cin, out_elems = (size_t)M * sh->cout;
+
+    std::mt19937 rng(123);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<uint16_t> h_in(in_elems), h_w((size_t)n_rows * k_pad, 0), h_res(out_elems);
+    std::vector<float> h_b(n_rows, 0.f);
+    for (auto& v : h_in) v = f32_to_bf16(nd(rng));
+    for (auto& v : h_res) v = f32_to_bf16(nd(rng));
+    const float wstd = 1.0f / sqrtf((float)k_real);
+    for (int n = 0; n < sh->cout; ++n) {
+        h_b[n] = 0.1f * nd(rng);
+        for (int t = 0; t < sh->k * sh->k; ++t)
+            for (int c = 0; c < sh->cin; ++c) h_w[(size_t)n * k_pad + t * cin_pad + c] = f32_to_bf16(wstd * nd(rng));
+    }
+    uint16_t *d_in, *d_w, *d_res, *d_out, *d_ref, *d_zero;
+    float* d_b;
+    CK(hipMalloc(&d_in, in_elems * 2 + 4096));
+    CK(hipMalloc(&d_w, h_w.size() * 2));
+    CK(hipMalloc(&d_res, out_elems * 2));
+    CK(hipMalloc(&d_out, out_elems * 2));
+    CK(hipMalloc(&d_ref, out_elems * 2));
+    CK(hipMalloc(&d_b, n_rows * 4));
+    CK(hipMalloc(&d_zero, 256));
+    CK(hipMemset(d_zero, 0, 256));
+    CK(hipMemcpy(d_in, h_in.data(), in_elems * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_w, h_w.data(), h_w.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_res, h_res.data(), out_elems * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_b, h_b.data(), n_rows * 4, hipMemcpyHostToDevice));
+
+    {
+        const long long total = M * sh->cout;
+        hipLaunchKernelGGL(ref_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, d_in, d_w, d_b,
+                           sh->res ? d_res : nullptr, d_ref, sh->b, sh->h, sh->w, sh->cin, Ho, Wo, sh->cout, sh->k,
+                           sh->s, pad, k_pad, cin_pad);
+        CK(hipDeviceSynchronize());
+    }
+    std::vector<uint16_t> h_ref(out_elems), h_out(out_elems);
+    CK(hipMemcpy(h_ref.data(), d_ref, out_elems * 2, hipMemcpyDeviceToHost));
+
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d_in; a.wgt = d_w; a.bias = d_b; a.out = d_out; a.res = sh->res ? d_res : nullptr; a.zero = d_zero;
+    a.ld_in = sh->cin; a.ld_out = sh->cout; a.ld_res = sh->cout;
+    a.H = sh->h; a.W = sh->w; a.C8 = cin_pad / 8; a.Ho = Ho; a.Wo = Wo; a.HoWo = Ho * Wo;
+    a.M = (int)M; a.N = sh->cout; a.n_rows = n_rows; a.k_pad = k_pad; a.ntaps = sh->k * sh->k; a.kw = sh->k;
+    a.stride = sh->s; a.pad = pad; a.act = 1; a.out_f32 = 0;
+    const double flops = 2.0 * (double)M * sh->cout * k_real;
+    const size_t dbg_words = 8 * 16 * 4096;
+    unsigned long long* d_dbg;
+    CK(hipMalloc(&d_dbg, dbg_words * 8));
+    CK(hipMemset(d_dbg, 0, dbg_words * 8));
+    a.dbg = d_dbg;
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    printf("%s: M=%lld N=%d K=%d (%.1f GFLOP)\n", sh->name, M, sh->cout, k_real, flops / 1e9);
+    for (int cfg : cfgs) {
+        CK(hipMemset(d_out, 0xff, out_elems * 2));
+        hipError_t e = conv_launch(cfg, a, 0);
+        if (e != hipSuccess) { printf("  cfg %2d launch failed: %s\n", cfg, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h_out.data(), d_out, out_elems * 2, hipMemcpyDeviceToHost));
+        double max_err = 0, max_ref = 0;
+        size_t bad = 0;
+        for (size_t i = 0; i < out_elems; ++i) {
+            const float r = bf16_to_f32(h_ref[i]), o = bf16_to_f32(h_out[i]);
+            const double d = fabs((double)r - (double)o);
+            if (!(d <= 0.02 * fabs(r) + 0.02)) ++bad;
+            if (d > max_err || d != d) max_err = d;
+            if (fabs(r) > max_ref) max_ref = fabs(r);
+        }
+        float best = 1e30f, tot = 0;
+        const int reps = 3;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters; ++i) (void)conv_launch(cfg, a, 0);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= iters;
+            tot += ms;
+            if (ms < best) best = ms;
+        }
+        printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
+               cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
+               bad ? "  <-- MISMATCH" : "");
+        if (cfg < 0) {
+            // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
+            std::vector<unsigned long long> h(dbg_words);
+            CK(hipMemcpy(h.data(), d_dbg, dbg_words * 8, hipMemcpyDeviceToHost));
+            double sum[6] = {0, 0, 0, 0, 0, 0}, steps = 0;
+            int waves = 0;
+            for (size_t w = 0; w < dbg_words / 8; ++w) {
+                if (!h[w * 8 + 6]) continue;
+                ++waves;
+                steps += (double)h[w * 8 + 6];
+                for (int k = 0; k < 6; ++k) sum[k] += (double)h[w * 8 + k];
+            }
+            static const char* nm[6] = {"half1 (reads Y + mfma X)", "waitcnt vmcnt/lgkmcnt", "barrier", "half2 (dma + reads X + mfma Y)",
+                                        "advance", "epilogue (amortised)"};
+            double tot = 0;
+            for (int k = 0; k < 6; ++k) tot += sum[k];
+            printf("    %d waves, %.0f steps each; cycles per step: total %.0f\n", waves, steps / waves, tot / steps);
+            for (int k = 0; k < 6; ++k) printf("      %-34s %8.1f  (%4.1f%%)\n", nm[k], sum[k] / steps, 100 * sum[k] / tot);
+            CK(hipMemset(d_dbg, 0, dbg_words * 8));
+        }
+        fflush(stdout);
+    }
+    return 0;
+}

@@ -11,7 +11,7 @@ acc = {}
 for f in sorted(glob.glob('gpurun_out/pmc/%s_p*/p_counter_collection.csv' % tag)):
     byc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'conv_igemm' in r['Kernel_Name']:
+        if 'conv_igemm' in r['Kernel_Name'] or 'conv_v2' in r['Kernel_Name']:
             byc[r['Counter_Name']].append(r)
     for c, rs in byc.items():
         sel = rs[-3:]
