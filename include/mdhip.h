@@ -155,16 +155,36 @@ typedef struct {
     double  flops;          /* algorithmic FLOPs of the op for the last (n,h,w)   */
     double  bytes;          /* algorithmic HBM bytes (read input once + write output once + weights) */
     int32_t cfg;            /* tile configuration chosen                      */
+    int32_t ntaps, stride, has_res;   /* conv: kh*kw of the packed kernel, stride, residual added */
 } mdhip_op_info;
 
 int mdhip_num_ops(mdhip_ctx* ctx);
 int mdhip_get_op_info(mdhip_ctx* ctx, int op, mdhip_op_info* out);
 /* run the forward with a hipEvent pair around every op; ms[op] = duration in milliseconds */
 int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hip_stream);
+/* live measurement for bench.py: with enable != 0 every mdhip_forward is bracketed by a hipEvent pair
+ * recorded on the stream it is launched on (a ring of the 64 most recent forwards);
+ * mdhip_forward_times waits for and returns the durations (ms) of the most recent min(max_n, 64,
+ * forwards since enabling) forwards, oldest first, and returns how many it wrote (or a negative code). */
+int mdhip_time_forwards(mdhip_ctx* ctx, int enable);
+int mdhip_forward_times(mdhip_ctx* ctx, float* ms, int max_n);
 /* force tile configuration `cfg` for op `op` (-1 = automatic choice); returns MDHIP_EINVAL
  * when cfg does not fit the op.  mdhip_num_conv_cfgs() = number of configurations. */
 int mdhip_set_op_cfg(mdhip_ctx* ctx, int op, int cfg);
 int mdhip_num_conv_cfgs(void);
+/* 1 when tile configuration `cfg` can run conv op `op` (the first-generation configurations run every
+ * op; the later main loops need C_in >= 64 or 32, kernels up to 3x3), 0 when not, negative on bad arguments */
+int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg);
+/* measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json): a conv whose GEMM
+ * shape matches an entry exactly runs configuration `cfg`; everything else uses the built-in heuristic.
+ * A configuration that does not support the op falls back to the heuristic choice. */
+typedef struct {
+    int32_t m, n, k;        /* GEMM view: M = batch*Ho*Wo, N = C_out, K = kh*kw*C_in */
+    int32_t ntaps, stride;  /* kh*kw, conv stride */
+    int32_t has_res;        /* 1 when the op adds a residual */
+    int32_t cfg;
+} mdhip_tuned;
+int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n);
 /* time one op in isolation: `iters` back-to-back launches bracketed by events */
 int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float* ms_avg,
                   void* hip_stream);

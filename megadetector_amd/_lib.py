@@ -44,7 +44,13 @@ class mdhip_letterbox(C.Structure):
 class mdhip_op_info(C.Structure):
     _fields_ = [('name', C.c_char * 48), ('kind', C.c_int32), ('layer', C.c_int32),
                 ('m', C.c_int32), ('n', C.c_int32), ('k', C.c_int32),
-                ('flops', C.c_double), ('bytes', C.c_double), ('cfg', C.c_int32)]
+                ('flops', C.c_double), ('bytes', C.c_double), ('cfg', C.c_int32),
+                ('ntaps', C.c_int32), ('stride', C.c_int32), ('has_res', C.c_int32)]
+
+
+class mdhip_tuned(C.Structure):
+    _fields_ = [('m', C.c_int32), ('n', C.c_int32), ('k', C.c_int32), ('ntaps', C.c_int32),
+                ('stride', C.c_int32), ('has_res', C.c_int32), ('cfg', C.c_int32)]
 
 
 #: every symbol include/mdhip.h declares: name -> (restype, argtypes)
@@ -67,8 +73,12 @@ SYMBOLS = {
     'mdhip_num_ops': (C.c_int, [_P]),
     'mdhip_get_op_info': (C.c_int, [_P, C.c_int, C.POINTER(mdhip_op_info)]),
     'mdhip_forward_timed': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'mdhip_time_forwards': (C.c_int, [_P, C.c_int]),
+    'mdhip_forward_times': (C.c_int, [_P, _P, C.c_int]),
     'mdhip_set_op_cfg': (C.c_int, [_P, C.c_int, C.c_int]),
     'mdhip_num_conv_cfgs': (C.c_int, []),
+    'mdhip_op_supports_cfg': (C.c_int, [_P, C.c_int, C.c_int]),
+    'mdhip_set_tuned': (C.c_int, [_P, C.POINTER(mdhip_tuned), C.c_int]),
     'mdhip_time_op': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     'mdhip_version': (C.c_char_p, []),
 }

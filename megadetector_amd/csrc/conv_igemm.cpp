@@ -411,11 +411,22 @@ static const ConvCfg g_cfgs[] = {
 #undef X
 };
 
-// configuration ids: [0, kNumV1) = this file's kernel, [kNumV1, ...) = conv_v2.cpp
+// configuration ids: [0, kNumV1) = this file's kernel, then conv_v2.cpp's, then conv_v3.cpp's
 constexpr int kNumV1 = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
 int conv_num_v1_cfgs() { return kNumV1; }
-int conv_num_cfgs() { return kNumV1 + conv2_num_cfgs(); }
-const ConvCfg& conv_cfg(int i) { return i < kNumV1 ? g_cfgs[i] : conv2_cfg(i - kNumV1); }
+int conv_num_cfgs() { return kNumV1 + conv2_num_cfgs() + conv3_num_cfgs(); }
+const ConvCfg& conv_cfg(int i) {
+    if (i < kNumV1) return g_cfgs[i];
+    if (i < kNumV1 + conv2_num_cfgs()) return conv2_cfg(i - kNumV1);
+    return conv3_cfg(i - kNumV1 - conv2_num_cfgs());
+}
+
+bool conv_supports(int cfg, const ConvArgs& a) {
+    if (cfg < 0 || cfg >= conv_num_cfgs()) return false;
+    if (cfg < kNumV1) return true;                                  // the first-generation kernel takes every op
+    if (cfg < kNumV1 + conv2_num_cfgs()) return conv2_supports(a);
+    return conv3_supports(a);
+}
 
 hipError_t conv_init() {
     hipError_t e = hipSuccess;
@@ -426,13 +437,18 @@ hipError_t conv_init() {
     MDHIP_CONV_CFGS(X)
 #undef X
     if (e == hipSuccess) e = conv2_init();
+    if (e == hipSuccess) e = conv3_init();
     return e;
 }
 
 hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
-    // negative ids -1, -2, ... address conv_v2.cpp's instrumented variants (developer tools only)
+    // negative ids address the developer variants (tools/convbench.cpp): -1, -2, ... conv_v2.cpp's,
+    // -101, -102, ... conv_v3.cpp's
     if (cfg >= conv_num_cfgs()) return hipErrorInvalidValue;
-    if (cfg >= kNumV1 || cfg < 0) return conv2_launch(cfg < 0 ? conv2_num_cfgs() - 1 - cfg : cfg - kNumV1, a, s);
+    if (cfg <= -101) return conv3_launch(conv3_num_cfgs() - 101 - cfg, a, s);
+    if (cfg < 0) return conv2_launch(conv2_num_cfgs() - 1 - cfg, a, s);
+    if (cfg >= kNumV1 + conv2_num_cfgs()) return conv3_launch(cfg - kNumV1 - conv2_num_cfgs(), a, s);
+    if (cfg >= kNumV1) return conv2_launch(cfg - kNumV1, a, s);
     const ConvCfg& c = g_cfgs[cfg];
     ConvArgs p = a;
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;

@@ -98,6 +98,12 @@ struct mdhip_ctx {
     int last_n = 0, last_h = 0, last_w = 0;
     std::string err;
     std::vector<hipEvent_t> events;
+    std::vector<mdhip_tuned> tuned;   // measured tile choices (tools/autotune.py), exact-shape matches only
+    // optional event pair around every mdhip_forward (bench.py's live roofline measurement)
+    static constexpr int kFwdRing = 64;
+    bool time_forward = false;
+    hipEvent_t fwd_ev[kFwdRing][2] = {};
+    long long fwd_count = 0;
     // pinned host staging: letterbox geometry ring + asynchronous NMS result slots
     LetterboxDev* geom_host = nullptr;
     int geom_slot = 0;
@@ -564,9 +570,27 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
         case OP_CONV: {
             ConvArgs a;
             fill_conv_args(ctx, op, n, h, w, a);
-            const int cfg = op.forced_cfg >= 0 ? op.forced_cfg : choose_cfg(a.M, a.n_rows);
+            int cfg = op.forced_cfg;
+            bool from_table = false;
+            if (cfg < 0) {
+                const PackedConv& pc = ctx->packed[op.pc];
+                for (const mdhip_tuned& t : ctx->tuned)
+                    if (t.m == a.M && t.n == pc.c_out && t.k == pc.k_real && t.ntaps == a.ntaps && t.stride == a.stride &&
+                        t.has_res == (op.has_res ? 1 : 0)) {
+                        cfg = t.cfg;
+                        from_table = true;
+                        break;
+                    }
+            }
+            if (cfg < 0) cfg = choose_cfg(a.M, a.n_rows);
+            hipError_t le = conv_launch(cfg, a, s);
+            if (le == hipErrorInvalidValue && from_table) {      // table entry from another build: not applicable
+                (void)hipGetLastError();
+                cfg = choose_cfg(a.M, a.n_rows);
+                le = conv_launch(cfg, a, s);
+            }
             op.last_cfg = cfg;
-            HIP_TRY(ctx, conv_launch(cfg, a, s));
+            HIP_TRY(ctx, le);
             break;
         }
         case OP_POOL: {
@@ -747,6 +771,9 @@ void mdhip_destroy(mdhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    for (int i = 0; i < mdhip_ctx::kFwdRing; ++i)
+        for (int k = 0; k < 2; ++k)
+            if (ctx->fwd_ev[i][k]) (void)hipEventDestroy(ctx->fwd_ev[i][k]);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->warena) (void)hipFree(ctx->warena);
     if (ctx->stage) (void)hipFree(ctx->stage);
@@ -828,12 +855,42 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     if (int rc = check_shape(ctx, n, h, w)) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int slot = (int)(ctx->fwd_count % mdhip_ctx::kFwdRing);
+    if (ctx->time_forward) HIP_TRY(ctx, hipEventRecord(ctx->fwd_ev[slot][0], s));
     for (Op& op : ctx->ops)
         if (int rc = run_op(ctx, op, n, h, w, s)) return rc;
+    if (ctx->time_forward) {
+        HIP_TRY(ctx, hipEventRecord(ctx->fwd_ev[slot][1], s));
+        ++ctx->fwd_count;
+    }
     ctx->last_n = n;
     ctx->last_h = h;
     ctx->last_w = w;
     return MDHIP_OK;
+}
+
+int mdhip_time_forwards(mdhip_ctx* ctx, int enable) {
+    if (!ctx) return MDHIP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (enable && !ctx->fwd_ev[0][0])
+        for (int i = 0; i < mdhip_ctx::kFwdRing; ++i)
+            for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreate(&ctx->fwd_ev[i][k]));
+    ctx->time_forward = enable != 0;
+    ctx->fwd_count = 0;
+    return MDHIP_OK;
+}
+
+int mdhip_forward_times(mdhip_ctx* ctx, float* ms, int max_n) {
+    if (!ctx || !ms || max_n < 0) return MDHIP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long have = std::min<long long>(ctx->fwd_count, mdhip_ctx::kFwdRing);
+    const int n = (int)std::min<long long>(have, max_n);
+    for (int i = 0; i < n; ++i) {                       // the most recent n forwards, oldest first
+        const int slot = (int)((ctx->fwd_count - n + i) % mdhip_ctx::kFwdRing);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->fwd_ev[slot][1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->fwd_ev[slot][0], ctx->fwd_ev[slot][1]));
+    }
+    return n;
 }
 
 int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hip_stream) {
@@ -1016,10 +1073,34 @@ int mdhip_get_op_info(mdhip_ctx* ctx, int op, mdhip_op_info* out) {
     out->flops = o.flops;
     out->bytes = o.bytes;
     out->cfg = o.last_cfg;
+    if (o.kind == OP_CONV) {
+        const PackedConv& pc = ctx->packed[o.pc];
+        out->ntaps = pc.kh * pc.kw;
+        out->stride = o.stride;
+        out->has_res = o.has_res ? 1 : 0;
+    }
     return MDHIP_OK;
 }
 
 int mdhip_num_conv_cfgs(void) { return conv_num_cfgs(); }
+
+int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg) {
+    if (!ctx || op < 0 || op >= (int)ctx->ops.size()) return MDHIP_EINVAL;
+    if (ctx->ops[op].kind != OP_CONV || cfg < 0 || cfg >= conv_num_cfgs()) return 0;
+    ConvArgs a;
+    const int h = ctx->last_h ? ctx->last_h : ctx->max_stride, w = ctx->last_w ? ctx->last_w : ctx->max_stride;
+    fill_conv_args(ctx, ctx->ops[op], ctx->last_n ? ctx->last_n : 1, h, w, a);
+    return conv_supports(cfg, a) ? 1 : 0;
+}
+
+int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n) {
+    if (!ctx || n < 0 || (n > 0 && !entries)) return MDHIP_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (entries[i].cfg < 0 || entries[i].cfg >= conv_num_cfgs())
+            return fail(ctx, MDHIP_EINVAL, "tuned entry %d: cfg %d outside [0,%d)", i, entries[i].cfg, conv_num_cfgs());
+    ctx->tuned.assign(entries, entries + n);
+    return MDHIP_OK;
+}
 
 int mdhip_set_op_cfg(mdhip_ctx* ctx, int op, int cfg) {
     if (!ctx || op < 0 || op >= (int)ctx->ops.size()) return MDHIP_EINVAL;

@@ -59,6 +59,7 @@ const ConvCfg& conv_cfg(int i);
 // returns hipSuccess or the launch error
 hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s);
 hipError_t conv_init();   // one-off: raise dynamic-LDS limits
+bool conv_supports(int cfg, const ConvArgs& a);   // can configuration `cfg` run this op?
 int conv_num_v1_cfgs();   // ids below this run conv_igemm.cpp's kernel (every shape); the rest conv_v2.cpp's
 // second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
 int conv2_num_cfgs();
@@ -66,6 +67,12 @@ const ConvCfg& conv2_cfg(int i);
 bool conv2_supports(const ConvArgs& a);
 hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s);
 hipError_t conv2_init();
+// third-generation main loop (conv_v3.cpp): 32-deep slabs, 4-stage ring, counted waits
+int conv3_num_cfgs();
+const ConvCfg& conv3_cfg(int i);
+bool conv3_supports(const ConvArgs& a);
+hipError_t conv3_launch(int cfg, const ConvArgs& a, hipStream_t s);
+hipError_t conv3_init();
 
 // ---------------------------------------------------------------------------------------
 // memory-bound helpers (misc_kernels.cpp)

@@ -5,6 +5,8 @@ All arithmetic happens in libmdhip.so (hand-written HIP); nothing here computes.
 """
 
 import ctypes as C
+import json
+import os
 
 import numpy as np
 
@@ -69,6 +71,32 @@ class HipContext:
         self.no = weights.nc + 5
         self.has_detect = specs[-1].type == MDHIP_DETECT
         self.max_stride = self.lib.mdhip_max_stride(self.h)
+        self.load_tuned()
+
+    TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_cfgs.json')
+
+    def load_tuned(self, path=None):
+        """
+        Hands the measured tile choices (tools/autotune.py) to the library; returns the number of
+        entries.  Shapes without an entry use the built-in heuristic, so a missing or stale file only
+        costs speed.
+        """
+        path = path or self.TUNED_PATH
+        if not os.path.exists(path):
+            return 0
+        try:
+            entries = json.load(open(path)).get('entries', [])
+        except Exception:
+            return 0
+        ncfg = self.lib.mdhip_num_conv_cfgs()
+        entries = [e for e in entries if 0 <= int(e['cfg']) < ncfg]
+        arr = (_lib.mdhip_tuned * max(1, len(entries)))()
+        for i, e in enumerate(entries):
+            arr[i].m, arr[i].n, arr[i].k = int(e['m']), int(e['n']), int(e['k'])
+            arr[i].ntaps, arr[i].stride = int(e['ntaps']), int(e['stride'])
+            arr[i].has_res, arr[i].cfg = int(e['has_res']), int(e['cfg'])
+        self._check(self.lib.mdhip_set_tuned(self.h, arr, len(entries)), 'mdhip_set_tuned')
+        return len(entries)
 
     # -- plumbing ---------------------------------------------------------------------
     def _check(self, rc, what):
@@ -182,7 +210,8 @@ class HipContext:
             info = _lib.mdhip_op_info()
             self._check(self.lib.mdhip_get_op_info(self.h, i, C.byref(info)), 'mdhip_get_op_info')
             res.append(dict(op=i, name=info.name.decode(), kind=info.kind, layer=info.layer, m=info.m,
-                            n=info.n, k=info.k, flops=info.flops, bytes=info.bytes, cfg=info.cfg))
+                            n=info.n, k=info.k, flops=info.flops, bytes=info.bytes, cfg=info.cfg,
+                            ntaps=info.ntaps, stride=info.stride, has_res=info.has_res))
         return res
 
     def forward_timed(self, n, h, w, stream=0):
@@ -191,8 +220,23 @@ class HipContext:
                     'mdhip_forward_timed')
         return ms
 
+    def time_forwards(self, enable=True):
+        """bracket every forward() with a HIP event pair on its stream (see forward_times)"""
+        self._check(self.lib.mdhip_time_forwards(self.h, 1 if enable else 0), 'mdhip_time_forwards')
+
+    def forward_times(self, max_n=64):
+        """durations (ms) of the most recent forwards measured since time_forwards(True), oldest first"""
+        ms = np.zeros((max_n,), dtype=np.float32)
+        n = self.lib.mdhip_forward_times(self.h, _lib.np_ptr(ms), int(max_n))
+        if n < 0:
+            self._check(n, 'mdhip_forward_times')
+        return ms[:n].copy()
+
     def set_op_cfg(self, op, cfg):
         self._check(self.lib.mdhip_set_op_cfg(self.h, op, cfg), 'mdhip_set_op_cfg')
+
+    def op_supports_cfg(self, op, cfg):
+        return self.lib.mdhip_op_supports_cfg(self.h, int(op), int(cfg)) == 1
 
     def num_conv_cfgs(self):
         return self.lib.mdhip_num_conv_cfgs()

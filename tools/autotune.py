@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """
 Measures every implicit-GEMM tile configuration on every conv op of a model at a given
-(batch, size) on the GPU and records the fastest per op.  Output (json):
-  { "<MODEL>:<batch>:<size>": { "<op name>": cfg, ... } }   -> megadetector_amd/tuned_cfgs.json
+(batch, size) on the GPU and records the fastest per GEMM shape.  Output (json):
+  { "entries": [ {"m","n","k","ntaps","stride","has_res","cfg","ms","tflops"}, ... ] }
+      -> megadetector_amd/tuned_cfgs.json (loaded by HipContext, matched on the exact shape)
 plus a human-readable table (per op: ms and TFLOP/s per configuration).
 
 Run on the GPU box:  python tools/autotune.py --out gpurun_out/tuned_cfgs.json
@@ -24,7 +25,8 @@ def main():
     ap.add_argument('--model', default='YOLOV5X6_MD')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=1280)
-    ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'tuned_cfgs.json'))
     ap.add_argument('--table', default=None)
     args = ap.parse_args()
@@ -35,18 +37,20 @@ def main():
     B, S = args.batch, args.size
     W = weights_io.synthetic_weights(getattr(yolo_yaml, args.model), seed=0)
     ctx = HipContext(W, device=0, max_batch=B, max_h=S, max_w=S)
+    ctx.load_tuned('/nonexistent')      # measure against the heuristic, not an older table
+    ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
     x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda')
     ctx.preprocess([int(x[i].data_ptr()) for i in range(B)], [(S, S, S, S, 0, 0)] * B, S, S)
     ctx.forward(B, S, S)                       # real activations in every buffer
     infos = ctx.op_infos()
     ncfg = ctx.num_conv_cfgs()
-    best = {}
     lines = []
     cache = {}
+    entries = {}
     for o in infos:
         if o['kind'] != 0:
             continue
-        sig = (o['m'], o['n'], o['k'], o['name'].split()[-1], 'res' if '.cv2 3x3' in o['name'] else '')
+        sig = (o['m'], o['n'], o['k'], o['ntaps'], o['stride'], o['has_res'])
         if sig in cache:
             ms = cache[sig]
         else:
@@ -54,26 +58,28 @@ def main():
             for cfg in range(ncfg):
                 try:
                     ctx.set_op_cfg(o['op'], cfg)
-                    ms.append(ctx.time_op(o['op'], B, S, S, iters=args.iters))
+                    ms.append(min(ctx.time_op(o['op'], B, S, S, iters=args.iters) for _ in range(args.reps)))
                 except Exception:
                     ms.append(float('inf'))
             ctx.set_op_cfg(o['op'], -1)
             cache[sig] = ms
         b = int(np.argmin(ms))
-        best[o['name']] = b
         tf = [o['flops'] / (t * 1e-3) / 1e12 if np.isfinite(t) else 0.0 for t in ms]
+        entries[sig] = dict(m=sig[0], n=sig[1], k=sig[2], ntaps=sig[3], stride=sig[4], has_res=sig[5], cfg=b,
+                            ms=round(ms[b], 5), tflops=round(tf[b], 1))
         lines.append('{:34s} M={:8d} N={:5d} K={:6d} default={:2d} best={:2d} {:8.3f} ms {:7.1f} TF/s | '.format(
             o['name'], o['m'], o['n'], o['k'], o['cfg'], b, ms[b], tf[b]) +
             ' '.join('{:6.1f}'.format(t) for t in tf))
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
-    key = '{}:{}:{}'.format(args.model, B, S)
-    data = {}
+    data = {'entries': []}
     if os.path.exists(args.out):
         try:
             data = json.load(open(args.out))
         except Exception:
-            data = {}
-    data[key] = best
+            data = {'entries': []}
+    keep = [e for e in data.get('entries', [])
+            if (e['m'], e['n'], e['k'], e['ntaps'], e['stride'], e['has_res']) not in entries]
+    data = {'n_cfgs': ncfg, 'entries': keep + list(entries.values())}
     json.dump(data, open(args.out, 'w'), indent=1, sort_keys=True)
     table = args.table or (os.path.splitext(args.out)[0] + '_{}_{}_{}.txt'.format(args.model, B, S))
     with open(table, 'w') as f:

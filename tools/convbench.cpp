@@ -88,6 +88,7 @@ int main(int argc, char** argv) {
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "all")) { for (int j = 0; j < conv_num_cfgs(); ++j) cfgs.push_back(j); continue; }
         if (argv[i][0] == 'p') { cfgs.push_back(-1 - atoi(argv[i] + 1)); continue; }   // p0, p1: instrumented v2 variants
+        if (argv[i][0] == 'q') { cfgs.push_back(-101 - atoi(argv[i] + 1)); continue; } // q0, q1: v3 developer variants
         cfgs.push_back(atoi(argv[i]));
     }
     CK(conv_init());
@@ -184,9 +185,9 @@ int main(int argc, char** argv) {
             if (ms < best) best = ms;
         }
         printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
-               cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
+               cfg <= -101 ? conv3_cfg(conv3_num_cfgs() - 101 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
                bad ? "  <-- MISMATCH" : "");
-        if (cfg < 0) {
+        if (cfg < 0 && cfg > -101) {
             // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
             std::vector<unsigned long long> h(dbg_words);
             CK(hipMemcpy(h.data(), d_dbg, dbg_words * 8, hipMemcpyDeviceToHost));

@@ -24,9 +24,19 @@ if [ "$STAGE" = "all" ] || [ "$STAGE" = "bench" ]; then
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "prof" ]; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r1 -- \
-     python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/rocprof.log" 2>&1)
+     python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --lean > "$OLDPWD/gpurun_out/rocprof.log" 2>&1)
   find gpurun_out/prof -name "*stats*" | head >> gpurun_out/rocprof.log
   # keep only the small summaries
   find gpurun_out/prof -type f ! -name "*stats*" -size +2M -delete 2>/dev/null
+fi
+if [ "$STAGE" = "all" ] || [ "$STAGE" = "traffic" ]; then
+  # HBM bytes per step: counters only (no tracing), FETCH_SIZE and WRITE_SIZE in separate passes
+  R="$PWD"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --pmc $C -d "$R/gpurun_out/traffic_$C" -o t --output-format csv -- \
+       python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --lean > "$R/gpurun_out/traffic_$C.log" 2>&1)
+  done
+  python tools/hbm_traffic.py gpurun_out/traffic_FETCH_SIZE gpurun_out/traffic_WRITE_SIZE YOLOV5X6_MD:32:1280 gpurun_out/hbm_traffic.json > gpurun_out/hbm_traffic.log 2>&1
+  find gpurun_out/traffic_FETCH_SIZE gpurun_out/traffic_WRITE_SIZE -type f -size +1M -delete 2>/dev/null
 fi
 ls -la gpurun_out >> gpurun_out/env.log
