@@ -175,6 +175,10 @@ int mdhip_num_conv_cfgs(void);
 /* 1 when tile configuration `cfg` can run conv op `op` (the first-generation configurations run every
  * op; the later main loops need C_in >= 64 or 32, kernels up to 3x3), 0 when not, negative on bad arguments */
 int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg);
+/* 1 when configuration `cfg` accumulates K in the canonical (r, s, c) order, i.e. produces bit-identical
+ * results to every other such configuration; 0 for the row-patch kernel, whose K order is
+ * (channel group, r, s, c) and whose results agree to fp32 summation-order rounding only */
+int mdhip_cfg_is_bitwise(int cfg);
 /* measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json): a conv whose GEMM
  * shape matches an entry exactly runs configuration `cfg`; everything else uses the built-in heuristic.
  * A configuration that does not support the op falls back to the heuristic choice. */

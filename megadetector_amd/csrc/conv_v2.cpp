@@ -429,9 +429,9 @@ conv_v2_kernel(const ConvArgs p) {
     X(9, 160, 160, 2, 2, 1)  \
     X(10, 320, 160, 4, 2, 1) \
     X(11, 160, 160, 2, 2, 54) \
-    X(12, 160, 160, 2, 2, 102) \
-    X(13, 320, 160, 4, 2, 102) \
-    X(14, 320, 160, 4, 2, 38)
+    X(12, 320, 160, 4, 2, 22) \
+    X(13, 320, 160, 4, 2, 16) \
+    X(14, 160, 160, 2, 2, 16)
 
 static const ConvCfg g_cfgs2[] = {
 #define X(id, bm, bn, wm, wn)                                                                        \

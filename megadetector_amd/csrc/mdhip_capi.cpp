@@ -45,6 +45,8 @@ struct Tensor {
 
 struct PackedConv {
     size_t w_off = 0, b_off = 0;     // byte offsets into the weight arena
+    size_t w4_off = 0;               // second packing for the row-patch kernel (0 = none)
+    int k_pad4 = 0, groups = 0;
     int n_rows = 0, k_pad = 0, cin_pad = 0, kh = 0, kw = 0, c_out = 0, k_real = 0;
 };
 
@@ -145,6 +147,7 @@ struct Planner {
     const mdhip_model* model;
     size_t cursor = 0;
     std::vector<std::vector<uint16_t>> w_host;   // packed weights per PackedConv
+    std::vector<std::vector<uint16_t>> w4_host;  // row-patch packing (empty when not applicable)
     std::vector<std::vector<float>> b_host;
     std::vector<int> layer_c, layer_div;
     std::vector<int> concat_target, concat_choff;   // per producer layer
@@ -221,8 +224,22 @@ struct Planner {
             }
             row0 += c->c_out;
         }
+        // 3x3 convs with at least 64 input channels (a multiple of 32) also get the row-patch order:
+        // k = (channel group of 64, tap, channel in group), every (group, tap) slab 64 wide (zero padded)
+        std::vector<uint16_t> w4;
+        if (!s2d_stem && pc.kh == 3 && pc.kw == 3 && pc.cin_pad >= 64 && pc.cin_pad % 32 == 0) {
+            pc.groups = (pc.cin_pad + 63) / 64;
+            pc.k_pad4 = pc.groups * 9 * 64;
+            w4.assign((size_t)pc.n_rows * pc.k_pad4, 0);
+            for (int o = 0; o < pc.n_rows; ++o)
+                for (int t = 0; t < 9; ++t)
+                    for (int ci = 0; ci < pc.cin_pad; ++ci)
+                        w4[(size_t)o * pc.k_pad4 + ((ci / 64) * 9 + t) * 64 + (ci % 64)] =
+                            w[(size_t)o * pc.k_pad + t * pc.cin_pad + ci];
+        }
         ctx->packed.push_back(pc);
         w_host.push_back(std::move(w));
+        w4_host.push_back(std::move(w4));
         b_host.push_back(std::move(b));
         return (int)ctx->packed.size() - 1;
     }
@@ -556,6 +573,9 @@ void fill_conv_args(mdhip_ctx* ctx, Op& op, int n, int h, int w, ConvArgs& a) {
     a.ld_res = op.has_res ? op.res.ld : 0;
     a.tiles_n = 1;
     a.dbg = nullptr;
+    a.wgt4 = pc.w4_off ? (const uint16_t*)(ctx->warena + pc.w4_off) : nullptr;
+    a.k_pad4 = pc.k_pad4;
+    a.groups = pc.groups;
     op.gm = a.M;
     op.gn = pc.c_out;
     op.gk = pc.k_real;
@@ -726,6 +746,10 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
         wcur = align_up(wcur + P.w_host[i].size() * 2, 256);
         ctx->packed[i].b_off = wcur;
         wcur = align_up(wcur + P.b_host[i].size() * 4, 256);
+        if (!P.w4_host[i].empty()) {
+            ctx->packed[i].w4_off = wcur;
+            wcur = align_up(wcur + P.w4_host[i].size() * 2, 256);
+        }
     }
     ctx->warena_bytes = wcur;
 
@@ -755,6 +779,8 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     for (size_t i = 0; i < ctx->packed.size(); ++i) {
         CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].w_off, P.w_host[i].data(), P.w_host[i].size() * 2, hipMemcpyHostToDevice));
         CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].b_off, P.b_host[i].data(), P.b_host[i].size() * 4, hipMemcpyHostToDevice));
+        if (!P.w4_host[i].empty())
+            CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].w4_off, P.w4_host[i].data(), P.w4_host[i].size() * 2, hipMemcpyHostToDevice));
     }
     ctx->nms_scr.keys[0] = (uint32_t*)(ctx->arena + nms_kv[0]);
     ctx->nms_scr.keys[1] = (uint32_t*)(ctx->arena + nms_kv[1]);
@@ -1092,6 +1118,8 @@ int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg) {
     fill_conv_args(ctx, ctx->ops[op], ctx->last_n ? ctx->last_n : 1, h, w, a);
     return conv_supports(cfg, a) ? 1 : 0;
 }
+
+int mdhip_cfg_is_bitwise(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs() && conv_cfg_is_bitwise_family(cfg)) ? 1 : 0; }
 
 int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n) {
     if (!ctx || n < 0 || (n > 0 && !entries)) return MDHIP_EINVAL;

@@ -44,6 +44,9 @@ struct ConvArgs {
     int act;                // 1 = SiLU
     int out_f32;            // 1 = fp32 output, no rounding (Detect logits)
     int tiles_n, tiles_m, tiles_per_xcd, m_streams;   // filled by conv_launch
+    // row-patch direct convolution (conv_v4.cpp): weights packed [n_rows][groups*9*64], k = (cg, r, s, c % 64)
+    const uint16_t* wgt4;   // nullptr when the op has no such packing
+    int k_pad4, groups;
     void* dbg;              // instrumentation output of the profiling variants (tools/convbench.cpp), else nullptr
 };
 
@@ -59,7 +62,8 @@ const ConvCfg& conv_cfg(int i);
 // returns hipSuccess or the launch error
 hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s);
 hipError_t conv_init();   // one-off: raise dynamic-LDS limits
-bool conv_supports(int cfg, const ConvArgs& a);   // can configuration `cfg` run this op?
+bool conv_supports(int cfg, const ConvArgs& a);
+bool conv_cfg_is_bitwise_family(int cfg);   // false: same result up to fp32 summation order only   // can configuration `cfg` run this op?
 int conv_num_v1_cfgs();   // ids below this run conv_igemm.cpp's kernel (every shape); the rest conv_v2.cpp's
 // second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
 int conv2_num_cfgs();
@@ -73,6 +77,12 @@ const ConvCfg& conv3_cfg(int i);
 bool conv3_supports(const ConvArgs& a);
 hipError_t conv3_launch(int cfg, const ConvArgs& a, hipStream_t s);
 hipError_t conv3_init();
+// row-patch direct convolution for 3x3 / stride 1 (conv_v4.cpp)
+int conv4_num_cfgs();
+const ConvCfg& conv4_cfg(int i);
+bool conv4_supports(int cfg, const ConvArgs& a);
+hipError_t conv4_launch(int cfg, const ConvArgs& a, hipStream_t s);
+hipError_t conv4_init();
 
 // ---------------------------------------------------------------------------------------
 // memory-bound helpers (misc_kernels.cpp)

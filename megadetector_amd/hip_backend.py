@@ -238,6 +238,9 @@ class HipContext:
     def op_supports_cfg(self, op, cfg):
         return self.lib.mdhip_op_supports_cfg(self.h, int(op), int(cfg)) == 1
 
+    def cfg_is_bitwise(self, cfg):
+        return self.lib.mdhip_cfg_is_bitwise(int(cfg)) == 1
+
     def num_conv_cfgs(self):
         return self.lib.mdhip_num_conv_cfgs()
 

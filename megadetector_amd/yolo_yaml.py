@@ -122,3 +122,7 @@ YOLOV5S_MD = make_yaml(0.33, 0.50, nc=3, p6=False)
 
 #: small P6 network for fast tests (same module mix as x6, ~1/60 of the FLOPs)
 YOLOV5N6_TEST = make_yaml(0.33, 0.25, nc=3, p6=True)
+
+#: wider small P6 network (hidden widths 64..256 at strides 8 and 16): exercises the kernels that need
+#: at least 64 input channels (row-patch 3x3) in the tests
+YOLOV5S6_TEST = make_yaml(0.33, 0.50, nc=3, p6=True)

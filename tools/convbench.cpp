@@ -88,6 +88,7 @@ int main(int argc, char** argv) {
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "all")) { for (int j = 0; j < conv_num_cfgs(); ++j) cfgs.push_back(j); continue; }
         if (argv[i][0] == 'p') { cfgs.push_back(-1 - atoi(argv[i] + 1)); continue; }   // p0, p1: instrumented v2 variants
+        if (argv[i][0] == 'r') { cfgs.push_back(-201 - atoi(argv[i] + 1)); continue; } // r0, r1: v4 developer variants
         if (argv[i][0] == 'q') { cfgs.push_back(-101 - atoi(argv[i] + 1)); continue; } // q0, q1: v3 developer variants
         cfgs.push_back(atoi(argv[i]));
     }
@@ -113,6 +114,17 @@ int main(int argc, char** argv) {
         for (int t = 0; t < sh->k * sh->k; ++t)
             for (int c = 0; c < sh->cin; ++c) h_w[(size_t)n * k_pad + t * cin_pad + c] = f32_to_bf16(wstd * nd(rng));
     }
+    // second weight packing for the row-patch kernel: k = (channel group of 64, tap, channel in group)
+    const int groups = (cin_pad + 63) / 64, k_pad4 = groups * 9 * 64;
+    std::vector<uint16_t> h_w4;
+    if (sh->k == 3) {
+        h_w4.assign((size_t)n_rows * k_pad4, 0);
+        for (int n = 0; n < sh->cout; ++n)
+            for (int t = 0; t < 9; ++t)
+                for (int c = 0; c < sh->cin; ++c)
+                    h_w4[(size_t)n * k_pad4 + ((c / 64) * 9 + t) * 64 + (c % 64)] = h_w[(size_t)n * k_pad + t * cin_pad + c];
+    }
+    uint16_t* d_w4 = nullptr;
     uint16_t *d_in, *d_w, *d_res, *d_out, *d_ref, *d_zero;
     float* d_b;
     CK(hipMalloc(&d_in, in_elems * 2 + 4096));
@@ -127,6 +139,10 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_w, h_w.data(), h_w.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_res, h_res.data(), out_elems * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_b, h_b.data(), n_rows * 4, hipMemcpyHostToDevice));
+    if (!h_w4.empty()) {
+        CK(hipMalloc(&d_w4, h_w4.size() * 2));
+        CK(hipMemcpy(d_w4, h_w4.data(), h_w4.size() * 2, hipMemcpyHostToDevice));
+    }
 
     {
         const long long total = M * sh->cout;
@@ -145,6 +161,7 @@ int main(int argc, char** argv) {
     a.H = sh->h; a.W = sh->w; a.C8 = cin_pad / 8; a.Ho = Ho; a.Wo = Wo; a.HoWo = Ho * Wo;
     a.M = (int)M; a.N = sh->cout; a.n_rows = n_rows; a.k_pad = k_pad; a.ntaps = sh->k * sh->k; a.kw = sh->k;
     a.stride = sh->s; a.pad = pad; a.act = 1; a.out_f32 = 0;
+    a.wgt4 = d_w4; a.k_pad4 = k_pad4; a.groups = groups;
     const double flops = 2.0 * (double)M * sh->cout * k_real;
     const size_t dbg_words = 8 * 16 * 4096;
     unsigned long long* d_dbg;
@@ -185,7 +202,7 @@ int main(int argc, char** argv) {
             if (ms < best) best = ms;
         }
         printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
-               cfg <= -101 ? conv3_cfg(conv3_num_cfgs() - 101 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
+               cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg <= -101 ? conv3_cfg(conv3_num_cfgs() - 101 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
                bad ? "  <-- MISMATCH" : "");
         if (cfg < 0 && cfg > -101) {
             // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
