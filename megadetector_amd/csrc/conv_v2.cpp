@@ -255,57 +255,91 @@ conv_v2_kernel(const ConvArgs p) {
                 r[i] = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
             }
         };
-        if constexpr (HAS_RES) fetch_res(0, rbuf[0]);
+        // bias of all fragment columns first (scalar loads), then pixel-row by pixel-row so that the
+        // stores that complete one cache line are issued back to back
+        float bv[FN][4];
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            if constexpr (HAS_RES) {
-                if (j + 1 < FN) fetch_res(j + 1, rbuf[(j + 1) & 1]);
-            }
             const int nb = n0 + wn * TN + j * 16;                // wave-uniform: bias comes through s_load
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
             if (nb < p.n_rows) {
-                // 16 biases of this fragment column through the scalar cache (explicit s_load: the
-                // compiler will not use the scalar path for memory it cannot prove read-only, and a
-                // vector load here would put a vmcnt(0) in front of the stores)
                 f32x16 b16;
                 const unsigned long long ba = (unsigned long long)(p.bias + nb);
                 const unsigned long long bs =
                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) |
                     (unsigned)__builtin_amdgcn_readfirstlane((int)ba);
                 asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b16) : "s"(bs) : "memory");
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    bv[r] = q4 == 0 ? b16[r] : (q4 == 1 ? b16[4 + r] : (q4 == 2 ? b16[8 + r] : b16[12 + r]));
+                const f32x4 g0 = {b16[0], b16[1], b16[2], b16[3]}, g1 = {b16[4], b16[5], b16[6], b16[7]},
+                            g2 = {b16[8], b16[9], b16[10], b16[11]}, g3 = {b16[12], b16[13], b16[14], b16[15]};
+                const f32x4 g = q4 == 0 ? g0 : (q4 == 1 ? g1 : (q4 == 2 ? g2 : g3));
+                bv[j][0] = g[0]; bv[j][1] = g[1]; bv[j][2] = g[2]; bv[j][3] = g[3];
             }
-            const int n = nbase + j * 16;
+        }
+        uint2 rrow[2][FN];
+        auto fetch_res_row = [&](int i, uint2 (&r)[FN]) {
+            const int m = min(m0 + i * 16, p.M - 1);
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + i * 16;
-                float v0 = acc[i][j][0] + bv[0];
-                float v1 = acc[i][j][1] + bv[1];
-                float v2 = acc[i][j][2] + bv[2];
-                float v3 = acc[i][j][3] + bv[3];
+            for (int j = 0; j < FN; ++j) r[j] = *(const uint2*)(p.res + (size_t)m * p.ld_res + min(nbase + j * 16, p.N - 4));
+        };
+        if constexpr (HAS_RES) fetch_res_row(0, rrow[0]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (HAS_RES) {
+                if (i + 1 < FM) fetch_res_row(i + 1, rrow[(i + 1) & 1]);
+            }
+            const int m = m0 + i * 16;
+            float v[FN][4];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] + bv[j][r];
+                    if ((PROF & 4) == 0 && p.act) t = silu_f32(t);
+                    v[j][r] = t;
+                }
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if ((PROF & 4) == 0 && p.act) {
-                    v0 = silu_f32(v0); v1 = silu_f32(v1); v2 = silu_f32(v2); v3 = silu_f32(v3);
-                }
                 if constexpr (HAS_RES) {
-                    const uint2 rv = rbuf[j & 1][i];
-                    v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                    v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
-                    v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                    v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+                    const uint2 rv = rrow[i & 1][j];
+                    v[j][0] += bf16_to_f32((uint16_t)(rv.x & 0xffff));
+                    v[j][1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+                    v[j][2] += bf16_to_f32((uint16_t)(rv.y & 0xffff));
+                    v[j][3] += bf16_to_f32((uint16_t)(rv.y >> 16));
                 }
-                if (m >= p.M || n >= p.N) continue;
-                if constexpr ((PROF & 2) != 0) {
-                    asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
-                } else if constexpr (OUT_F32) {
-                    *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v0, v1, v2, v3);
-                } else {
+            }
+            if constexpr ((PROF & 2) != 0) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(v[j][0]), "v"(v[j][1]), "v"(v[j][2]), "v"(v[j][3]));
+            } else if constexpr (OUT_F32) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = nbase + j * 16;
+                    if (m < p.M && n < p.N)
+                        *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                }
+            } else {
+                // bf16: pairs of fragment columns are exchanged across the four 16-lane rows
+                // (v_permlane32_swap, v_permlane16_swap) so that a lane holds 8 consecutive channels
+                // = 16 bytes, and one store covers 64 contiguous bytes per pixel instead of 32
+                uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
+#pragma unroll
+                for (int j = 0; j + 1 < FN; j += 2) {
+                    unsigned a0 = pack2_bf16(v[j][0], v[j][1]), a1 = pack2_bf16(v[j][2], v[j][3]);
+                    unsigned b0 = pack2_bf16(v[j + 1][0], v[j + 1][1]), b1 = pack2_bf16(v[j + 1][2], v[j + 1][3]);
+                    auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
+                    auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+                    // row q of the wave now holds channels q*8 .. q*8+7 of the 32 channels of this pair
+                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
+                    if (m < p.M && n < p.N) *(uint4*)(orow + n) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+                if (FN & 1) {
+                    const int j = FN - 1;
+                    const int n = nbase + j * 16;
                     uint2 o;
-                    o.x = pack2_bf16(v0, v1);
-                    o.y = pack2_bf16(v2, v3);
-                    *(uint2*)((uint16_t*)p.out + (size_t)m * p.ld_out + n) = o;
+                    o.x = pack2_bf16(v[j][0], v[j][1]);
+                    o.y = pack2_bf16(v[j][2], v[j][3]);
+                    if (m < p.M && n < p.N) *(uint2*)(orow + n) = o;
                 }
             }
         }

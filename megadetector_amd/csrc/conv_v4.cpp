@@ -129,15 +129,17 @@ conv_v4_kernel(const ConvArgs p) {
     int l_step = 0;                                // the weight loader's step inside a tile (same for every tile)
     // every wave issues exactly B_PER pieces per step (no branches inside the step: the scheduling
     // groups below need one basic block); a surplus piece reads zeros into the dump slot
-    auto dma_b = [&](int stage) __attribute__((always_inline)) {
+    auto dma_b_piece = [&](int stage, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
+        const bool real = (B_PIECES % NW) == 0 || i < B_PER - 1 || wave < B_PIECES % NW;      // wave-uniform
+        lds_char* dst = smem + (real ? stage * B_BYTES + (i * NW + wave) * 1024 : DUMP_OFF);
+        MDHIP_DMA16(b_rsrc, dst, b_off[i], l_step * 128);
+    };
+    auto dma_b_done = [&]() __attribute__((always_inline)) { l_step = (l_step + 1 == steps_per_tile) ? 0 : l_step + 1; };
+    auto dma_b = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const bool real = (B_PIECES % NW) == 0 || i < B_PER - 1 || wave < B_PIECES % NW;      // wave-uniform
-            lds_char* dst = smem + (real ? stage * B_BYTES + (i * NW + wave) * 1024 : DUMP_OFF);
-            MDHIP_DMA16(b_rsrc, dst, b_off[i], l_step * 128);
-        }
-        l_step = (l_step + 1 == steps_per_tile) ? 0 : l_step + 1;
+        for (int i = 0; i < B_PER; ++i) dma_b_piece(stage, i);
+        dma_b_done();
     };
 
     // ---- patch loader: runs one channel group ahead of the consumer ----------------------------------
@@ -212,6 +214,10 @@ conv_v4_kernel(const ConvArgs p) {
             a_addr[i] = (unsigned)(P_OFF + buf * P_BYTES + idx * 128 + ((c0 ^ (idx & 7)) << 4));
         }
     };
+    auto set_a_addr_one = [&](int buf, int shift, int i) __attribute__((always_inline)) {
+        const int idx = fidx[i] + shift;
+        a_addr[i] = (unsigned)(P_OFF + buf * P_BYTES + idx * 128 + ((c0 ^ (idx & 7)) << 4));
+    };
     auto read_x = [&](int i, int kk) __attribute__((always_inline)) -> bf16x8 {
         return *(const __attribute__((address_space(3))) bf16x8*)(smem + (a_addr[i] ^ (unsigned)(kk * 64)));
     };
@@ -246,20 +252,13 @@ conv_v4_kernel(const ConvArgs p) {
             mrel[i] = o * p.W + (px - o * WT);
         }
         const int nbase = n0 + wn * TN + q4 * 4;
-        uint2 rbuf[2][FM];
-        auto fetch_res = [&](int j, uint2 (&r)[FM]) __attribute__((always_inline)) {
-            const int n = min(nbase + j * 16, p.N - 4);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) r[i] = *(const uint2*)(p.res + (size_t)(m_org + mrel[i]) * p.ld_res + n);
-        };
-        if constexpr (HAS_RES) fetch_res(0, rbuf[0]);
+        // bias of all fragment columns first (scalar loads), then pixel-row by pixel-row with 16-byte
+        // stores (see conv_v2.cpp's epilogue)
+        float bv[FN][4];
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            if constexpr (HAS_RES) {
-                if (j + 1 < FN) fetch_res(j + 1, rbuf[(j + 1) & 1]);
-            }
             const int nb = n0 + wn * TN + j * 16;                // wave-uniform
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
             if (nb < p.n_rows) {
                 f32x16 b16;
                 const unsigned long long ba = (unsigned long long)(p.bias + nb);
@@ -270,34 +269,69 @@ conv_v4_kernel(const ConvArgs p) {
                 const f32x4 g0 = {b16[0], b16[1], b16[2], b16[3]}, g1 = {b16[4], b16[5], b16[6], b16[7]},
                             g2 = {b16[8], b16[9], b16[10], b16[11]}, g3 = {b16[12], b16[13], b16[14], b16[15]};
                 const f32x4 g = q4 == 0 ? g0 : (q4 == 1 ? g1 : (q4 == 2 ? g2 : g3));
-                bv[0] = g[0]; bv[1] = g[1]; bv[2] = g[2]; bv[3] = g[3];
+                bv[j][0] = g[0]; bv[j][1] = g[1]; bv[j][2] = g[2]; bv[j][3] = g[3];
             }
-            const int n = nbase + j * 16;
+        }
+        uint2 rrow[2][FN];
+        auto fetch_res_row = [&](int i, uint2 (&r)[FN]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                float v0 = acc[i][j][0] + bv[0];
-                float v1 = acc[i][j][1] + bv[1];
-                float v2 = acc[i][j][2] + bv[2];
-                float v3 = acc[i][j][3] + bv[3];
+            for (int j = 0; j < FN; ++j)
+                r[j] = *(const uint2*)(p.res + (size_t)(m_org + mrel[i]) * p.ld_res + min(nbase + j * 16, p.N - 4));
+        };
+        if constexpr (HAS_RES) fetch_res_row(0, rrow[0]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (HAS_RES) {
+                if (i + 1 < FM) fetch_res_row(i + 1, rrow[(i + 1) & 1]);
+            }
+            float v[FN][4];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] + bv[j][r];
+                    if ((PROF & 4) == 0 && p.act) t = silu_f32(t);
+                    v[j][r] = t;
+                }
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if ((PROF & 4) == 0 && p.act) {
-                    v0 = silu_f32(v0); v1 = silu_f32(v1); v2 = silu_f32(v2); v3 = silu_f32(v3);
-                }
                 if constexpr (HAS_RES) {
-                    const uint2 rv = rbuf[j & 1][i];
-                    v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                    v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
-                    v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                    v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+                    const uint2 rv = rrow[i & 1][j];
+                    v[j][0] += bf16_to_f32((uint16_t)(rv.x & 0xffff));
+                    v[j][1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+                    v[j][2] += bf16_to_f32((uint16_t)(rv.y & 0xffff));
+                    v[j][3] += bf16_to_f32((uint16_t)(rv.y >> 16));
                 }
-                const unsigned voff = (n < p.N) ? (unsigned)(mrel[i] * p.ld_out + n) * (unsigned)esz : kOOB;
-                if constexpr ((PROF & 2) != 0) {
-                    asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(voff));
-                } else if constexpr (OUT_F32) {
-                    const u32x4 o = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
+            }
+            if constexpr ((PROF & 2) != 0) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(v[j][0]), "v"(v[j][1]), "v"(v[j][2]), "v"(v[j][3]));
+            } else if constexpr (OUT_F32) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = nbase + j * 16;
+                    const unsigned voff = (n < p.N) ? (unsigned)(mrel[i] * p.ld_out + n) * 4u : kOOB;
+                    const u32x4 o = {__float_as_uint(v[j][0]), __float_as_uint(v[j][1]), __float_as_uint(v[j][2]), __float_as_uint(v[j][3])};
                     __builtin_amdgcn_raw_buffer_store_b128(o, o_rsrc, voff, 0, 0);
-                } else {
-                    const u32x2 o = {pack2_bf16(v0, v1), pack2_bf16(v2, v3)};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j + 1 < FN; j += 2) {
+                    const unsigned a0 = pack2_bf16(v[j][0], v[j][1]), a1 = pack2_bf16(v[j][2], v[j][3]);
+                    const unsigned b0 = pack2_bf16(v[j + 1][0], v[j + 1][1]), b1 = pack2_bf16(v[j + 1][2], v[j + 1][3]);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    const auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
+                    const auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
+                    const unsigned voff = (n < p.N) ? (unsigned)(mrel[i] * p.ld_out + n) * 2u : kOOB;
+                    const u32x4 o = {t0[0], t1[0], t0[1], t1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, o_rsrc, voff, 0, 0);
+                }
+                if (FN & 1) {
+                    const int j = FN - 1;
+                    const int n = nbase + j * 16;
+                    const unsigned voff = (n < p.N) ? (unsigned)(mrel[i] * p.ld_out + n) * 2u : kOOB;
+                    const u32x2 o = {pack2_bf16(v[j][0], v[j][1]), pack2_bf16(v[j][2], v[j][3])};
                     __builtin_amdgcn_raw_buffer_store_b64(o, o_rsrc, voff, 0, 0);
                 }
             }
@@ -331,53 +365,67 @@ conv_v4_kernel(const ConvArgs p) {
     // barrier (and the DMA issue gets no MFMA cover).  None of the reads of a half is consumed inside
     // that half, so the fences do not create waits.
     int tap = 0, cg = 0, pbuf = 0, c_tile = first_tile;
+    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if constexpr ((PROF & 1) != 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            t_acc[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if constexpr ((PROF & 1) != 0) t_prev = __builtin_amdgcn_s_memtime();
 #define MDHIP_V4_MFMA(W, X, E0, E1)                                                                   \
     _Pragma("unroll") for (int e = (E0); e < (E1); ++e)                                              \
         acc[e % FM][e / FM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[e / FM], X[e % FM], acc[e % FM][e / FM], 0, 0, 0);
 #define MDHIP_FENCE() __builtin_amdgcn_sched_barrier(0)
     for (int step = 0; step < total_steps; ++step) {
         const int cur = step & 1;
-        // ---- first half: k 0..31 of this step, while its k 32..63 fragments are read ----------------
+        const bool wrap = tap == 8;
+        const int ntap = wrap ? 0 : tap + 1;
+        const int nbuf = wrap ? pbuf ^ 1 : pbuf;
+        const int nr = ntap / 3;
+        const int nshift = nr * PW + (ntap - nr * 3);
+        // ---- first half: k 0..31 of this step, while its k 32..63 fragments are read and the patch
+        //      addresses of the next tap are computed ---------------------------------------------------
 #pragma unroll
         for (int g = 0; g < FM; ++g) {
             xb[g] = read_x(g, 1);
             wb[g] = read_w(cur, 1, g);
+            set_a_addr_one(nbuf, nshift, g);
             MDHIP_FENCE();
             MDHIP_V4_MFMA(wa, xa, g * FN, (g + 1) * FN)
             MDHIP_FENCE();
         }
 
+        stamp(0);
         // everything this wave requested has landed; its reads of weight stage `cur` are complete
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(1);
         __builtin_amdgcn_s_barrier();
+        stamp(2);
         MDHIP_FENCE();
 
-        // ---- second half: weight slab of step+2, one piece of the next group's patch, the k 0..31
-        //      fragments of step+1 (possibly the next group's first tap), MFMAs on k 32..63 ------------
-        const bool wrap = tap == 8;
-        const int ntap = wrap ? 0 : tap + 1;
-        const int nbuf = wrap ? pbuf ^ 1 : pbuf;
-        static_assert(B_PER + 1 <= FN, "DMA pieces are paired with the first MFMAs of the half");
-        dma_b(cur);
-        MDHIP_FENCE();
-        MDHIP_V4_MFMA(wb, xb, 0, B_PER)
-        MDHIP_FENCE();
-        dma_patch_tap(pbuf ^ 1, tap);
-        set_a_addr(nbuf, ntap);
-        MDHIP_FENCE();
-        MDHIP_V4_MFMA(wb, xb, B_PER, FN)
-        MDHIP_FENCE();
+        // ---- second half: the k 0..31 fragments of step+1 (possibly the next group's first tap) and
+        //      MFMAs on k 32..63; one DMA piece (weight slab of step+2, then one piece of the next
+        //      group's patch) behind every group of MFMAs, so that the eight waves' requests do not
+        //      arrive as one burst -----------------------------------------------------------------------
+        static_assert(B_PER + 1 <= FM, "one DMA piece per MFMA group");
 #pragma unroll
         for (int g = 0; g < FM; ++g) {
             xa[g] = read_x(g, 0);
             wa[g] = read_w(cur ^ 1, 0, g);
             MDHIP_FENCE();
-            MDHIP_V4_MFMA(wb, xb, FN + g * (FN - 1), FN + (g + 1) * (FN - 1))
+            MDHIP_V4_MFMA(wb, xb, g * FN, (g + 1) * FN)
+            MDHIP_FENCE();
+            if (g < B_PER) dma_b_piece(cur, g);
+            if (g == B_PER) dma_patch_tap(pbuf ^ 1, tap);
             MDHIP_FENCE();
         }
+        dma_b_done();
 #undef MDHIP_V4_MFMA
 #undef MDHIP_FENCE
 
+        stamp(3);
         if (wrap) {                            // the group is done: the loader moves on, maybe the tile too
             patch_next_group();
             if (++cg == G) {
@@ -388,6 +436,14 @@ conv_v4_kernel(const ConvArgs p) {
         }
         tap = ntap;
         pbuf = nbuf;
+        stamp(5);
+    }
+    if constexpr ((PROF & 1) != 0) {
+        if (lane == 0 && p.dbg) {
+            unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+            for (int k = 0; k < 6; ++k) d[k] = t_acc[k];
+            d[6] = (unsigned long long)total_steps;
+        }
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -399,8 +455,8 @@ conv_v4_kernel(const ConvArgs p) {
 #define MDHIP_CONV4_CFGS(X) X(0, 8, 40, 0)
 #define MDHIP_CONV4_PROF(X) \
     X(1, 8, 40, 22)         \
-    X(2, 8, 40, 150)        \
-    X(3, 8, 40, 6)
+    X(2, 8, 40, 1)          \
+    X(3, 8, 40, 23)
 
 static const ConvCfg g_cfgs4[] = {
 #define X(id, r, wt, prof) \

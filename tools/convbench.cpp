@@ -204,7 +204,7 @@ int main(int argc, char** argv) {
         printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
                cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg <= -101 ? conv3_cfg(conv3_num_cfgs() - 101 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
                bad ? "  <-- MISMATCH" : "");
-        if (cfg < 0 && cfg > -101) {
+        if (cfg < 0 && (cfg > -101 || cfg <= -201)) {
             // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
             std::vector<unsigned long long> h(dbg_words);
             CK(hipMemcpy(h.data(), d_dbg, dbg_words * 8, hipMemcpyDeviceToHost));
