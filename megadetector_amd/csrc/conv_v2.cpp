@@ -385,17 +385,27 @@ conv_v2_kernel(const ConvArgs p) {
     if constexpr ((PROF & 1) != 0) t_prev = __builtin_amdgcn_s_memtime();
     for (int step = 0; step < total_steps; ++step) {
         const int cur = step & 1;
+        // The instruction mix of a step is pinned with sched_barrier(0) fences: left alone the compiler
+        // sinks all fragment reads below the MFMAs of a half (the wave then waits for them at the
+        // barrier) and issues the DMA pieces as one burst.  None of the reads of a half is consumed
+        // inside that half, so the fences create no waits.  MFMA chunk g = fragment column g.
+        constexpr int DMA_TOTAL = A_PER + B_PER, DMA_PER_G = (DMA_TOTAL + FN - 1) / FN;
         // ---- first half: k 0..31 of slab `step`, while its k 32..63 fragments are read ----------
 #pragma unroll
-        for (int i = 0; i < FM; ++i) xb[i] = read_x(cur, 1, i);
+        for (int g = 0; g < FN; ++g) {
+            wb[g] = read_w(cur, 1, g);
+            if (g < FM) xb[g] = read_x(cur, 1, g);
+            if (g == FN - 1) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) wb[j] = read_w(cur, 1, j);
-        if constexpr ((PROF & 64) == 0) {
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
+                for (int i = FN; i < FM; ++i) xb[i] = read_x(cur, 1, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((PROF & 64) == 0) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+                    acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], xa[i], acc[i][g], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         stamp(0);
@@ -404,23 +414,31 @@ conv_v2_kernel(const ConvArgs p) {
         stamp(1);
         __builtin_amdgcn_s_barrier();
         stamp(2);
+        __builtin_amdgcn_sched_barrier(0);
 
-        // ---- second half: DMA of slab step+2 into stage cur, X fragments of slab step+1,
-        //      MFMAs on k 32..63 of slab step -------------------------------------------------------
+        // ---- second half: X fragments of slab step+1, MFMAs on k 32..63 of slab step, and the DMA
+        //      pieces of slab step+2 (into stage cur) spread behind the MFMA chunks --------------------
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) dma_a(cur, i);
+        for (int g = 0; g < FN; ++g) {
+            wa[g] = read_w(cur ^ 1, 0, g);
+            if (g < FM) xa[g] = read_x(cur ^ 1, 0, g);
+            if (g == FN - 1) {
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) dma_b(cur, i);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) xa[i] = read_x(cur ^ 1, 0, i);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) wa[j] = read_w(cur ^ 1, 0, j);
-        if constexpr ((PROF & 64) == 0) {
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
+                for (int i = FN; i < FM; ++i) xa[i] = read_x(cur ^ 1, 0, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((PROF & 64) == 0) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+                    acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], xb[i], acc[i][g], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = g * DMA_PER_G; d < (g + 1) * DMA_PER_G && d < DMA_TOTAL; ++d) {
+                if (d < A_PER) dma_a(cur, d);
+                else dma_b(cur, d - A_PER);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         stamp(3);

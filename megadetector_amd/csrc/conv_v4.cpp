@@ -456,7 +456,7 @@ conv_v4_kernel(const ConvArgs p) {
 #define MDHIP_CONV4_PROF(X) \
     X(1, 8, 40, 22)         \
     X(2, 8, 40, 1)          \
-    X(3, 8, 40, 23)
+    X(3, 8, 40, 2)
 
 static const ConvCfg g_cfgs4[] = {
 #define X(id, r, wt, prof) \
