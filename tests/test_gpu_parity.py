@@ -358,3 +358,52 @@ def test_detector_end_to_end_vs_oracle():
     res = det.generate_detections_one_batch([imgs[0], np.zeros((4, 4), np.uint8)], ['ok.jpg', 'bad.jpg'])
     assert res[1]['failure'] == 'image access failure' and res[1]['detections'] is None
     assert res[0]['detections'] is not None
+
+
+# ---------------------------------------------------------------------------------------
+# the batch driver on the real HIP detector: orchestration modes, JSON, failures
+# ---------------------------------------------------------------------------------------
+def test_batch_driver_modes_identical_on_gpu(tmp_path):
+    """
+    reference md_tests.py:1251,1267,1283 (queue / preprocess-queue / checkpoint runs must give the same
+    JSON as the plain run) and :1235-1238 (batched vs unbatched within 0.01 -- here: identical) with the
+    HIP detector behind load_detector, on JPEGs of two different shapes plus one unreadable file.
+    """
+    import json
+    from PIL import Image
+    from megadetector_amd import run_detector_batch as RDB
+    rng = np.random.default_rng(5)
+    names = []
+    for i in range(7):
+        shape = (120, 160, 3) if i % 2 else (150, 100, 3)
+        p = tmp_path / ('img_%02d.jpg' % i)
+        base = rng.integers(0, 256, (shape[0] // 10 + 1, shape[1] // 10 + 1, 3), dtype=np.uint8)
+        img = np.kron(base, np.ones((10, 10, 1), dtype=np.uint8))[:shape[0], :shape[1]]
+        Image.fromarray(img).save(p, quality=95)
+        names.append(str(p))
+    bad = tmp_path / 'broken.jpg'
+    bad.write_bytes(b'not a jpeg')
+    names.append(str(bad))
+    model = 'synthetic:YOLOV5N6_TEST:1'
+    opts = {'batch_size': 4}      # default 1280 px letterbox, as in the reference's batch mode
+
+    def run(**kw):
+        res = RDB.load_and_run_detector_batch(model, names, quiet=True, detector_options=dict(opts), **kw)
+        return json.loads(json.dumps(sorted(res, key=lambda r: r['file'])))
+
+    plain = run()
+    assert len(plain) == len(names)
+    assert [r for r in plain if r['file'].endswith('broken.jpg')][0].get('failure') == 'image access failure'
+    ok = [r for r in plain if 'failure' not in r]
+    assert len(ok) == 7 and all(isinstance(r['detections'], list) for r in ok)
+    for r in ok:
+        for d in r['detections']:
+            assert d['category'] in ('1', '2', '3') and 0.0 <= d['conf'] <= 1.0 and len(d['bbox']) == 4
+    for kw in (dict(batch_size=4), dict(use_image_queue=True), dict(use_image_queue=True, batch_size=3),
+               dict(use_image_queue=True, batch_size=3, preprocess_on_image_queue=True, loader_workers=2)):
+        assert run(**kw) == plain, kw
+    out = tmp_path / 'out.json'
+    RDB.write_results_to_file(plain, str(out), detector_file=model)
+    j = json.load(open(out))
+    assert j['info']['format_version'] == '1.6' and len(j['images']) == len(names)
+    assert j['detection_categories'] == {'1': 'animal', '2': 'person', '3': 'vehicle'}
