@@ -64,12 +64,13 @@ constexpr int v4_lds_bytes(int r, int wt, int bn) { return 2 * bn * 128 + 2 * v4
     __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr), 16, (voff), (soff), 0, 0)
 
 // PROF bits (developer builds only): 2 = no stores, 4 = no SiLU, 16 = no DMA in the steady state
-template <int R, int WT, int PROF = 0>
+template <int R, int WT, int WM, int WN, int PROF = 0>
 __global__ void __launch_bounds__(512, 2)
 conv_v4_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int WM = 4, WN = 2, NW = 8;
-    constexpr int BM = R * WT, BN = 160;
+    constexpr int NW = WM * WN;
+    static_assert(NW == 8, "eight waves per workgroup");
+    constexpr int BM = R * WT, BN = WN * 80;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int PW = WT + 2, PROWS = (R + 2) * PW;
@@ -78,7 +79,7 @@ conv_v4_kernel(const ConvArgs p) {
     constexpr int B_BYTES = BN * 128, B_PIECES = BN / 8, B_PER = (B_PIECES + NW - 1) / NW;
     constexpr int P_OFF = 2 * B_BYTES;
     constexpr int DUMP_OFF = P_OFF + 2 * P_BYTES;
-    static_assert(TM % 16 == 0 && TN % 16 == 0 && (TM % WT) == 0, "wave tile = whole tile rows, 16-pixel fragments");
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "16x16 fragments");
     static_assert(P_PER <= 9, "one patch piece per tap at most");
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
@@ -374,10 +375,9 @@ conv_v4_kernel(const ConvArgs p) {
         }
     };
     if constexpr ((PROF & 1) != 0) t_prev = __builtin_amdgcn_s_memtime();
-#define MDHIP_V4_MFMA(W, X, E0, E1)                                                                   \
-    _Pragma("unroll") for (int e = (E0); e < (E1); ++e)                                              \
-        acc[e % FM][e / FM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[e / FM], X[e % FM], acc[e % FM][e / FM], 0, 0, 0);
 #define MDHIP_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // a half-full last channel group (C_in mod 64 <= 32) has nothing in k 32..63: its second-half MFMAs are skipped
+    const bool tail_short = (p.C8 & 7) != 0 && (p.C8 & 7) <= 4;
     for (int step = 0; step < total_steps; ++step) {
         const int cur = step & 1;
         const bool wrap = tap == 8;
@@ -385,15 +385,21 @@ conv_v4_kernel(const ConvArgs p) {
         const int nbuf = wrap ? pbuf ^ 1 : pbuf;
         const int nr = ntap / 3;
         const int nshift = nr * PW + (ntap - nr * 3);
+        const bool skip_y = tail_short && cg == G - 1;
         // ---- first half: k 0..31 of this step, while its k 32..63 fragments are read and the patch
-        //      addresses of the next tap are computed ---------------------------------------------------
+        //      addresses of the next tap are computed; MFMA chunk g = fragment column g -----------------
 #pragma unroll
-        for (int g = 0; g < FM; ++g) {
-            xb[g] = read_x(g, 1);
+        for (int g = 0; g < FN; ++g) {
             wb[g] = read_w(cur, 1, g);
-            set_a_addr_one(nbuf, nshift, g);
+            if (g < FM) { xb[g] = read_x(g, 1); set_a_addr_one(nbuf, nshift, g); }
+            if (g == FN - 1) {
+#pragma unroll
+                for (int i = FN; i < FM; ++i) { xb[i] = read_x(i, 1); set_a_addr_one(nbuf, nshift, i); }
+            }
             MDHIP_FENCE();
-            MDHIP_V4_MFMA(wa, xa, g * FN, (g + 1) * FN)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], xa[i], acc[i][g], 0, 0, 0);
             MDHIP_FENCE();
         }
 
@@ -407,22 +413,29 @@ conv_v4_kernel(const ConvArgs p) {
 
         // ---- second half: the k 0..31 fragments of step+1 (possibly the next group's first tap) and
         //      MFMAs on k 32..63; one DMA piece (weight slab of step+2, then one piece of the next
-        //      group's patch) behind every group of MFMAs, so that the eight waves' requests do not
+        //      group's patch) behind every chunk of MFMAs, so that the eight waves' requests do not
         //      arrive as one burst -----------------------------------------------------------------------
-        static_assert(B_PER + 1 <= FM, "one DMA piece per MFMA group");
+        static_assert(B_PER + 1 <= FN, "one DMA piece per MFMA chunk");
 #pragma unroll
-        for (int g = 0; g < FM; ++g) {
-            xa[g] = read_x(g, 0);
+        for (int g = 0; g < FN; ++g) {
             wa[g] = read_w(cur ^ 1, 0, g);
+            if (g < FM) xa[g] = read_x(g, 0);
+            if (g == FN - 1) {
+#pragma unroll
+                for (int i = FN; i < FM; ++i) xa[i] = read_x(i, 0);
+            }
             MDHIP_FENCE();
-            MDHIP_V4_MFMA(wb, xb, g * FN, (g + 1) * FN)
+            if (!skip_y) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], xb[i], acc[i][g], 0, 0, 0);
+            }
             MDHIP_FENCE();
             if (g < B_PER) dma_b_piece(cur, g);
             if (g == B_PER) dma_patch_tap(pbuf ^ 1, tap);
             MDHIP_FENCE();
         }
         dma_b_done();
-#undef MDHIP_V4_MFMA
 #undef MDHIP_FENCE
 
         stamp(3);
@@ -451,16 +464,24 @@ conv_v4_kernel(const ConvArgs p) {
 // ---------------------------------------------------------------------------------------
 // configuration table
 // ---------------------------------------------------------------------------------------
-// id (local), tile rows, tile columns, PROF bits
-#define MDHIP_CONV4_CFGS(X) X(0, 8, 40, 0)
+// id (local), tile rows, tile columns, waves along M, waves along N (80 output channels each), PROF bits
+#define MDHIP_CONV4_CFGS(X) \
+    X(0, 8, 40, 4, 2, 0)    \
+    X(1, 8, 32, 8, 1, 0)
 #define MDHIP_CONV4_PROF(X) \
-    X(1, 8, 40, 22)         \
-    X(2, 8, 40, 1)          \
-    X(3, 8, 40, 2)
+    X(2, 8, 40, 4, 2, 22)   \
+    X(3, 8, 40, 4, 2, 1)    \
+    X(4, 8, 32, 8, 1, 1)
 
+struct V4Geom { int r, wt, bn; };
+static const V4Geom g_geom4[] = {
+#define X(id, r, wt, wm, wn, prof) {r, wt, (wn) * 80},
+    MDHIP_CONV4_CFGS(X) MDHIP_CONV4_PROF(X)
+#undef X
+};
 static const ConvCfg g_cfgs4[] = {
-#define X(id, r, wt, prof) \
-    {(r) * (wt), 160, 512, (size_t)v4_lds_bytes(r, wt, 160), 1, "v4:patch" #r "x" #wt "/160/" #prof},
+#define X(id, r, wt, wm, wn, prof) \
+    {(r) * (wt), (wn) * 80, 512, (size_t)v4_lds_bytes(r, wt, (wn) * 80), 1, "v4:patch" #r "x" #wt "/" #wm "x" #wn "/" #prof},
     MDHIP_CONV4_CFGS(X) MDHIP_CONV4_PROF(X)
 #undef X
 };
@@ -471,9 +492,9 @@ const ConvCfg& conv4_cfg(int i) { return g_cfgs4[i]; }
 
 hipError_t conv4_init() {
     hipError_t e = hipSuccess;
-#define X(id, r, wt, prof)                                                                     \
+#define X(id, r, wt, wm, wn, prof)                                                             \
     if (e == hipSuccess)                                                                     \
-        e = hipFuncSetAttribute((const void*)conv_v4_kernel<r, wt, prof>,                       \
+        e = hipFuncSetAttribute((const void*)conv_v4_kernel<r, wt, wm, wn, prof>,               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs4[id].lds_bytes);
     MDHIP_CONV4_CFGS(X) MDHIP_CONV4_PROF(X)
 #undef X
@@ -482,9 +503,9 @@ hipError_t conv4_init() {
 
 bool conv4_supports(int cfg, const ConvArgs& a) {
     if (cfg < 0 || cfg >= conv4_num_cfgs() + kNumProf4) return false;
-    const int r = 8, wt = 40;                                     // every configuration so far
+    const int r = g_geom4[cfg].r, wt = g_geom4[cfg].wt;
     return a.wgt4 != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H &&
-           a.Wo == a.W && (a.H % r) == 0 && (a.W % wt) == 0 && a.C8 >= 8 && (a.C8 % 4) == 0 && (a.N % 4) == 0 &&
+           a.Wo == a.W && (a.H % r) == 0 && (a.W % wt) == 0 && a.C8 >= 8 && (a.N % 8) == 0 &&
            (long long)(r + 2) * a.W * a.ld_in * 2 < 0x7fffffffLL && (long long)r * a.W * a.ld_out * 4 < 0x7fffffffLL;
 }
 
@@ -498,9 +519,9 @@ hipError_t conv4_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     p.m_streams = std::max(1, std::min(p.tiles_per_xcd, 32 / p.tiles_n));
     const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
     switch (cfg) {
-#define X(id, r, wt, prof)                                                                      \
+#define X(id, r, wt, wm, wn, prof)                                                              \
     case id:                                                                                  \
-        hipLaunchKernelGGL((conv_v4_kernel<r, wt, prof>), grid, dim3(512), c.lds_bytes, s, p); \
+        hipLaunchKernelGGL((conv_v4_kernel<r, wt, wm, wn, prof>), grid, dim3(512), c.lds_bytes, s, p); \
         break;
         MDHIP_CONV4_CFGS(X) MDHIP_CONV4_PROF(X)
 #undef X

@@ -224,10 +224,10 @@ struct Planner {
             }
             row0 += c->c_out;
         }
-        // 3x3 convs with at least 64 input channels (a multiple of 32) also get the row-patch order:
+        // 3x3 convs with at least 64 input channels also get the row-patch order:
         // k = (channel group of 64, tap, channel in group), every (group, tap) slab 64 wide (zero padded)
         std::vector<uint16_t> w4;
-        if (!s2d_stem && pc.kh == 3 && pc.kw == 3 && pc.cin_pad >= 64 && pc.cin_pad % 32 == 0) {
+        if (!s2d_stem && pc.kh == 3 && pc.kw == 3 && pc.cin_pad >= 64) {
             pc.groups = (pc.cin_pad + 63) / 64;
             pc.k_pad4 = pc.groups * 9 * 64;
             w4.assign((size_t)pc.n_rows * pc.k_pad4, 0);

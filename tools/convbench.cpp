@@ -45,6 +45,9 @@ static const Shape kShapes[] = {
     {"l1_s2", 32, 640, 640, 80, 160, 3, 2, false},      // M 3276800 N 160 K 720
     {"l3_s2", 32, 320, 320, 160, 320, 3, 2, false},
     {"l5_s2", 32, 160, 160, 320, 640, 3, 2, false},
+    {"p32", 2, 16, 64, 80, 80, 3, 1, true},             // row-patch kernels: short tail group, N = 80
+    {"p40", 2, 16, 80, 160, 160, 3, 1, false},          // 64 + 64 + 32 channels
+    {"p40b", 3, 8, 40, 96, 200, 3, 1, true},            // 64 + 32 channels, ragged N
     {"small", 2, 24, 40, 64, 96, 3, 1, true},
     {"small1", 2, 24, 40, 64, 96, 1, 1, false},
     {"smalls2", 2, 24, 40, 64, 96, 3, 2, false},
