@@ -212,13 +212,27 @@ def main():
                 traffic = None
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                'kernel': 'conv stack of one step = {} implicit-GEMM launches (conv_igemm_kernel / conv_v2_kernel / '
-                          'conv_v3_kernel instantiations), HIP events on the launch stream around mdhip_forward in '
+                'kernel': 'conv stack of one step = {} conv launches (conv_igemm_kernel / conv_v2_kernel / '
+                          'conv_v4_kernel instantiations), HIP events on the launch stream around mdhip_forward in '
                           'the timed region, mean of {} steps'.format(len(conv), len(fwd_ms_live)),
                 'flops_per_step': conv_flops, 'kernel_ms_per_step': round(fwd_ms, 3),
                 'per_op_conv_ms_per_step': None if args.lean else round(conv_ms, 3),
                 'per_op_conv_tflops': None if args.lean else round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                 'other_kernels_ms_per_step': None if args.lean else round(other_ms, 3)}
+        if not args.lean:
+            # the dominant kernel instantiation (by time) and its own rate, from the per-op events
+            by_cfg = {}
+            for o, t in conv:
+                e = by_cfg.setdefault(o['cfg'], [0, 0.0, 0.0])
+                e[0] += 1
+                e[1] += t
+                e[2] += o['flops']
+            top = max(by_cfg.items(), key=lambda kv: kv[1][1])
+            roof['dominant_kernel'] = {
+                'name': ctx.conv_cfg_name(top[0]), 'launches_per_step': top[1][0],
+                'ms_per_step': round(top[1][1], 3), 'avg_launch_us': round(top[1][1] / top[1][0] * 1e3, 2),
+                'flops_per_step': top[1][2], 'achieved_tflops': round(top[1][2] / (top[1][1] * 1e-3) / 1e12, 2),
+                'frac': round(top[1][2] / (top[1][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
         if args.model == 'YOLOV5X6_MD' and S == 1280:
             assert abs(conv_flops / B / 1e9 - GFLOP_PER_IMAGE_1280) < 0.05, conv_flops / B / 1e9
         if args.profile_out and not args.lean:

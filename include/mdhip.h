@@ -179,6 +179,8 @@ int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg);
  * results to every other such configuration; 0 for the row-patch kernel, whose K order is
  * (channel group, r, s, c) and whose results agree to fp32 summation-order rounding only */
 int mdhip_cfg_is_bitwise(int cfg);
+/* human-readable name of a tile configuration ("v2:160x160/2x2", ...); "" when out of range */
+const char* mdhip_conv_cfg_name(int cfg);
 /* measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json): a conv whose GEMM
  * shape matches an entry exactly runs configuration `cfg`; everything else uses the built-in heuristic.
  * A configuration that does not support the op falls back to the heuristic choice. */

@@ -1119,6 +1119,8 @@ int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg) {
     return conv_supports(cfg, a) ? 1 : 0;
 }
 
+const char* mdhip_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs()) ? conv_cfg(cfg).name : ""; }
+
 int mdhip_cfg_is_bitwise(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs() && conv_cfg_is_bitwise_family(cfg)) ? 1 : 0; }
 
 int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n) {

@@ -238,6 +238,9 @@ class HipContext:
     def op_supports_cfg(self, op, cfg):
         return self.lib.mdhip_op_supports_cfg(self.h, int(op), int(cfg)) == 1
 
+    def conv_cfg_name(self, cfg):
+        return self.lib.mdhip_conv_cfg_name(int(cfg)).decode()
+
     def cfg_is_bitwise(self, cfg):
         return self.lib.mdhip_cfg_is_bitwise(int(cfg)) == 1
 

@@ -148,34 +148,36 @@ def test_tile_configurations_agree_bitwise(n6):
 def test_row_patch_conv_matches_implicit_gemm_and_oracle():
     """
     The row-patch direct convolution (conv_v4.cpp) on every op it supports of a wider test network
-    at 640x640 (80x80 and 40x40 maps, 64..128 input channels incl. a half-full channel group):
+    at 640x1280 (80x160 and 40x80 maps, 64..128 input channels incl. a half-full channel group):
     against the implicit-GEMM result (same arithmetic, different fp32 summation order) and, layer by
     layer, against the bf16-emulating oracle.
     """
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.hip_backend import HipContext
     W = weights_io.synthetic_weights(yolo_yaml.YOLOV5S6_TEST, seed=3)
-    ctx = HipContext(W, device=0, max_batch=2, max_h=640, max_w=640)
+    HH, WW = 640, 1280          # 80x160 and 40x80 maps: divisible by both patch tile widths (40, 32) where C >= 64
+    ctx = HipContext(W, device=0, max_batch=2, max_h=HH, max_w=WW)
     try:
-        imgs = PU.structured_images(2, 640, 640, seed=21)
-        ctx.preprocess(imgs, _identity_geoms(imgs), 640, 640)
-        ctx.forward(2, 640, 640)
-        base = ctx.read_predictions(2, 640, 640).copy()
+        imgs = PU.structured_images(2, HH, WW, seed=21)
+        ctx.preprocess(imgs, _identity_geoms(imgs), HH, WW)
+        ctx.forward(2, HH, WW)
+        base = ctx.read_predictions(2, HH, WW).copy()
         convs = [o['op'] for o in ctx.op_infos() if o['kind'] == 0]
         patch_cfgs = [c for c in range(ctx.num_conv_cfgs()) if not ctx.cfg_is_bitwise(c)]
         assert patch_cfgs, 'no row-patch configuration in this build'
-        x, _ = PU.oracle_input(imgs, 640, 64)
+        x, _ = PU.oracle_input(imgs, WW, 64)
+        assert tuple(x.shape[2:]) == (HH, WW)
         keep = {}
         PU.oracle_forward(W, x, emulate_bf16=True, keep=keep)
         for cfg in patch_cfgs:
             switched = [op for op in convs if ctx.op_supports_cfg(op, cfg)]
-            assert len(switched) >= 4, (cfg, len(switched))
+            assert len(switched) >= 2, (cfg, len(switched))
             for op in convs:
                 ctx.set_op_cfg(op, cfg if op in switched else -1)
-            ctx.forward(2, 640, 640)
+            ctx.forward(2, HH, WW)
             infos = ctx.op_infos()
             assert all(infos[op]['cfg'] == cfg for op in switched)
-            got = ctx.read_predictions(2, 640, 640)
+            got = ctx.read_predictions(2, HH, WW)
             emax, emean = PU.rel_err(got[..., :4], base[..., :4])
             assert emax < LAYER_MAX_TOL and emean < LAYER_MEAN_TOL, (cfg, emax, emean)
             assert np.abs(got[..., 4:] - base[..., 4:]).max() < E2E_CONF_TOL_BF16_ORACLE, cfg
@@ -187,9 +189,10 @@ def test_row_patch_conv_matches_implicit_gemm_and_oracle():
                     bad.append((i,) + e)
             assert not bad, bad
             # batch-composition invariance stays bitwise with the patch kernel
-            ctx.preprocess([imgs[1]], _identity_geoms([imgs[1]]), 640, 640)
-            ctx.forward(1, 640, 640)
-            np.testing.assert_array_equal(ctx.read_predictions(1, 640, 640)[0], got[1])
+            ctx.preprocess([imgs[1]], _identity_geoms([imgs[1]]), HH, WW)
+            ctx.forward(1, HH, WW)
+            np.testing.assert_array_equal(ctx.read_predictions(1, HH, WW)[0], got[1])
+            ctx.preprocess(imgs, _identity_geoms(imgs), HH, WW)
     finally:
         ctx.close()
 
