@@ -161,13 +161,16 @@ def main():
                 for b in range(B)]
 
     def run(n_steps):
+        # two steps are kept queued on the GPU behind the running one, so that a slow moment of the host
+        # thread (formatting, a descheduled process) does not leave the GPU idle
         last = None
+        depth = 2
         for i in range(n_steps):
             enqueue(i)
-            if i > 0:
-                last = collect(i - 1)
-        if n_steps > 0:
-            last = collect(n_steps - 1)
+            if i >= depth:
+                last = collect(i - depth)
+        for i in range(max(0, n_steps - depth), n_steps):
+            last = collect(i)
         return last
 
     def barrier():
