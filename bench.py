@@ -246,7 +246,7 @@ def main():
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                 'kernel': 'conv stack of one step = {} conv launches (conv_igemm_kernel / conv_v2_kernel / '
-                          'conv_v4_kernel instantiations), HIP events on the launch stream around mdhip_forward in '
+                          'conv_v4_kernel / conv_v5_kernel instantiations), HIP events on the launch stream around mdhip_forward in '
                           'the timed region, mean of {} steps'.format(len(conv), len(fwd_ms_live)),
                 'flops_per_step': conv_flops, 'kernel_ms_per_step': round(fwd_ms, 3),
                 'per_op_conv_ms_per_step': None if args.lean else round(conv_ms, 3),

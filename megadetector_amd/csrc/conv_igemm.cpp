@@ -450,16 +450,18 @@ static const ConvCfg g_cfgs[] = {
 // configuration ids: [0, kNumV1) = this file's kernel, then conv_v2.cpp's, then conv_v3.cpp's
 constexpr int kNumV1 = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
 int conv_num_v1_cfgs() { return kNumV1; }
-int conv_num_cfgs() { return kNumV1 + conv2_num_cfgs() + conv3_num_cfgs() + conv4_num_cfgs(); }
+int conv_num_cfgs() { return kNumV1 + conv2_num_cfgs() + conv3_num_cfgs() + conv4_num_cfgs() + conv5_num_cfgs(); }
 const ConvCfg& conv_cfg(int i) {
     if (i < kNumV1) return g_cfgs[i];
     i -= kNumV1;
     if (i < conv2_num_cfgs()) return conv2_cfg(i);
     i -= conv2_num_cfgs();
     if (i < conv3_num_cfgs()) return conv3_cfg(i);
-    return conv4_cfg(i - conv3_num_cfgs());
+    i -= conv3_num_cfgs();
+    if (i < conv4_num_cfgs()) return conv4_cfg(i);
+    return conv5_cfg(i - conv4_num_cfgs());
 }
-// conv_v4.cpp's results agree with the implicit-GEMM kernels to rounding only (different K order)
+// conv_v4.cpp's and conv_v5.cpp's results agree with the implicit-GEMM kernels to rounding only (different K order)
 bool conv_cfg_is_bitwise_family(int cfg) { return cfg < kNumV1 + conv2_num_cfgs() + conv3_num_cfgs(); }
 
 bool conv_supports(int cfg, const ConvArgs& a) {
@@ -467,7 +469,9 @@ bool conv_supports(int cfg, const ConvArgs& a) {
     if (cfg < kNumV1) return true;                                  // the first-generation kernel takes every op
     if (cfg < kNumV1 + conv2_num_cfgs()) return conv2_supports(a);
     if (cfg < kNumV1 + conv2_num_cfgs() + conv3_num_cfgs()) return conv3_supports(a);
-    return conv4_supports(cfg - kNumV1 - conv2_num_cfgs() - conv3_num_cfgs(), a);
+    const int c4 = cfg - kNumV1 - conv2_num_cfgs() - conv3_num_cfgs();
+    if (c4 < conv4_num_cfgs()) return conv4_supports(c4, a);
+    return conv5_supports(c4 - conv4_num_cfgs(), a);
 }
 
 hipError_t conv_init() {
@@ -481,16 +485,20 @@ hipError_t conv_init() {
     if (e == hipSuccess) e = conv2_init();
     if (e == hipSuccess) e = conv3_init();
     if (e == hipSuccess) e = conv4_init();
+    if (e == hipSuccess) e = conv5_init();
     return e;
 }
 
 hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     // negative ids address the developer variants (tools/convbench.cpp): -1, -2, ... conv_v2.cpp's,
-    // -101, -102, ... conv_v3.cpp's, -201, ... conv_v4.cpp's
+    // -101, -102, ... conv_v3.cpp's, -201, ... conv_v4.cpp's, -301, ... conv_v5.cpp's
     if (cfg >= conv_num_cfgs()) return hipErrorInvalidValue;
+    if (cfg <= -301) return conv5_launch(conv5_num_cfgs() - 301 - cfg, a, s);
     if (cfg <= -201) return conv4_launch(conv4_num_cfgs() - 201 - cfg, a, s);
     if (cfg <= -101) return conv3_launch(conv3_num_cfgs() - 101 - cfg, a, s);
     if (cfg < 0) return conv2_launch(conv2_num_cfgs() - 1 - cfg, a, s);
+    if (cfg >= kNumV1 + conv2_num_cfgs() + conv3_num_cfgs() + conv4_num_cfgs())
+        return conv5_launch(cfg - kNumV1 - conv2_num_cfgs() - conv3_num_cfgs() - conv4_num_cfgs(), a, s);
     if (cfg >= kNumV1 + conv2_num_cfgs() + conv3_num_cfgs())
         return conv4_launch(cfg - kNumV1 - conv2_num_cfgs() - conv3_num_cfgs(), a, s);
     if (cfg >= kNumV1 + conv2_num_cfgs()) return conv3_launch(cfg - kNumV1 - conv2_num_cfgs(), a, s);

@@ -1,0 +1,527 @@
+// 3x3 / stride 1 convolution with *row-segment reuse* across the three taps of a kernel row
+// (gfx950 / MI355X).
+//
+// Why: the implicit-GEMM kernels gather every input pixel nine times through the L2 -> LDS path, which
+// is what bounds them.  An M tile is BM *consecutive* output pixels in raster
+// order, so for kernel row r the three taps (r,0) (r,1) (r,2) read three windows of the same
+// contiguous run of BM+2 input pixels, one pixel apart.  This kernel loads that run ONCE per
+// (64-channel group, kernel row) into an LDS buffer and serves the three taps from it by reading the
+// A fragments at a row shift of s: activation traffic / 2.95, 103 FLOP per L2->LDS byte for a
+// 128x160 tile instead of 71 -- in the two-workgroups-per-CU structure of conv_v2 (the row-patch
+// kernel conv_v4 reuses more but needs the whole CU for one lock-stepped workgroup).
+//
+// The run wraps around image-row ends (and image ends inside a batch): a tap that falls outside the
+// image for some output pixel must contribute zero.  That is not a property of the LDS image any
+// more, so it is handled at the fragment read: per tile every lane keeps a 9-bit tap-validity mask
+// for each of its FM pixels, and an invalid (pixel, tap) reads a 128-byte row of zeros instead
+// (one v_cndmask on the LDS address per fragment, no branches).
+//
+// K order is (channel group, r, s, channel in group) -- the second weight packing of conv_v4 -- so
+// results equal the row-patch kernel's and differ from the implicit-GEMM kernels by fp32 summation
+// order only.
+//
+// Schedule per step (= one tap of one channel group, 64 deep), as conv_v2:
+//     read  Y  (k 32..63: run buffer @ shift s, weight stage cur)   } interleaved
+//     mfma  X  (k 0..31)                                            }
+//     s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier
+//     DMA   weight slab of step+2 -> stage cur ; in steps s = 0, 1: pieces of the NEXT run
+//     read  X' (k 0..31 of step+1)                                  } interleaved
+//     mfma  Y                                                       }
+
+#include <algorithm>
+#include <type_traits>
+
+#include "mdhip_internal.h"
+
+namespace mdhip {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int kNumRecords = 0x7fffffff;
+
+__device__ __forceinline__ float silu_f32(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return *(const uint32_t*)&r;
+}
+
+constexpr int v5_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
+// 2 run buffers + 2 weight stages + 1 KiB holding the row of zeros
+constexpr int v5_lds_bytes(int bm, int bn) { return 2 * v5_run_pieces(bm) * 1024 + 2 * bn * 128 + 1024; }
+constexpr int v5_blocks_per_cu(int bm, int bn, int nw) {
+    int b = 163840 / v5_lds_bytes(bm, bn);
+    if (b > 32 / nw) b = 32 / nw;
+    if (b > 2) b = 2;
+    return b < 1 ? 1 : b;
+}
+constexpr int v5_waves_per_simd(int bm, int bn, int nw) {
+    int w = v5_blocks_per_cu(bm, bn, nw) * nw / 4;
+    return w < 1 ? 1 : w;
+}
+
+}  // namespace
+
+#define MDHIP_DMA16(rsrc, lptr, voff, soff) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr), 16, (voff), (soff), 0, 0)
+
+// PROF bits (developer builds only): 1 = s_memtime stamps, 2 = no stores, 4 = no SiLU, 16 = no DMA in the steady state
+template <int BM, int BN, int WM, int WN, int PROF = 0>
+__global__ void __launch_bounds__(WM * WN * 64, v5_waves_per_simd(BM, BN, WM * WN))
+conv_v5_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int A_PIECES = v5_run_pieces(BM), A_BUF = A_PIECES * 1024;
+    constexpr int A_PER = (A_PIECES + NW - 1) / NW;          // run pieces per wave (the last one may not exist)
+    constexpr int A_H0 = (A_PER + 1) / 2;                    // issued in step s = 0; the rest in step s = 1
+    constexpr int B_BYTES = BN * 128, B_PIECES = BN / 8, B_PER = (B_PIECES + NW - 1) / NW;
+    constexpr int B_OFF = 2 * A_BUF;
+    constexpr int ZERO_OFF = B_OFF + 2 * B_BYTES;
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "16x16 fragments");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lds_char* const smem = (lds_char*)smem_generic;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- persistent streams (see conv_igemm.cpp): block b runs on XCD b % 8 ---------------------
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_n = slot % p.tiles_n;
+    const int ms = slot / p.tiles_n;
+    const int xcd_first = xcd * p.tiles_per_xcd;
+    const int xcd_tiles = min(p.tiles_per_xcd, p.tiles_m - xcd_first);
+    const int my_tiles = (xcd_tiles > ms) ? (xcd_tiles - ms + p.m_streams - 1) / p.m_streams : 0;
+    if (my_tiles <= 0) return;
+    const int first_tile = xcd_first + ms;
+    const int tile_step = p.m_streams;
+    const int last_tile = first_tile + (my_tiles - 1) * tile_step;
+    const int n0 = tile_n * BN;
+    const int G = p.groups;                       // 64-channel groups (the last one may be half full)
+    const int runs_per_tile = 3 * G;              // (channel group, kernel row) pairs
+    const int steps_per_tile = 9 * G;
+    const int total_runs = my_tiles * runs_per_tile;
+
+    // the row of zeros that invalid (pixel, tap) pairs read
+    if (tid < 64) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+
+    // ---- weight stream: slab (cg, tap) = 128 bytes of every row at byte offset step * 128 ---------
+    const int lr = lane >> 3;
+    const int jj = (lane & 7) ^ lr;
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.wgt4 + (size_t)n0 * p.k_pad4), 0, kNumRecords, 0x00020000);
+    unsigned b_off[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int row = (i * NW + wave) * 8 + lr;
+        b_off[i] = (row < BN && n0 + row < p.n_rows) ? (unsigned)(row * p.k_pad4 + jj * 8) * 2u : kOOB;
+    }
+    int l_step = 0;                                // the weight loader's step inside a tile (same for every tile)
+    auto dma_b_piece = [&](int stage, int i) __attribute__((always_inline)) {
+        if constexpr ((PROF & 16) != 0) return;
+        if ((B_PIECES % NW) != 0 && i == B_PER - 1 && wave >= B_PIECES % NW) return;           // wave-uniform
+        MDHIP_DMA16(b_rsrc, smem + B_OFF + stage * B_BYTES + (i * NW + wave) * 1024, b_off[i], l_step * 128);
+    };
+    auto dma_b_done = [&]() __attribute__((always_inline)) { l_step = (l_step + 1 == steps_per_tile) ? 0 : l_step + 1; };
+
+    // ---- run loader: one (group, kernel row) ahead of the consumer ------------------------------------
+    // Buffer row q of run (tile, cg, r) holds input pixel  tile*BM + (r-1)*W - 1 + q  (raster index over
+    // the whole batch), channels cg*64 .. cg*64+63.  Pixels outside the batch read zeros; pixels that
+    // are inside the batch but outside the image for some tap are dealt with at the fragment read.
+    __amdgpu_buffer_rsrc_t a_rsrc = b_rsrc;
+    unsigned q_off[A_PER];                         // byte offset of this lane's pixel + chunk from the run's first pixel
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int q = (i * NW + wave) * 8 + lr;
+        q_off[i] = (unsigned)(q * p.ld_in * 2 + jj * 16);
+    }
+    int lg_tile = first_tile, lg_cg = 0, lg_r = 0;
+    bool lg_live = true;
+    int lg_first = 0;                              // raster index of the run's first pixel (may be negative)
+    unsigned lg_soff = 0;
+    auto run_tile = [&](int t) __attribute__((always_inline)) {
+        const long long origin = (long long)t * BM - p.W - 1;          // first pixel of the r = 0 run
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + origin * p.ld_in), 0, kNumRecords, 0x00020000);
+    };
+    auto run_setup = [&]() __attribute__((always_inline)) {
+        lg_first = lg_tile * BM + (lg_r - 1) * p.W - 1;
+        lg_soff = (unsigned)(lg_r * p.W * p.ld_in * 2 + lg_cg * 128);
+    };
+    auto dma_run_piece = [&](int buf, int i) __attribute__((always_inline)) {
+        if constexpr ((PROF & 16) != 0) return;
+        if (i * NW + wave >= A_PIECES) return;                                                  // wave-uniform
+        const int q = (i * NW + wave) * 8 + lr;
+        const bool ok = lg_live && (unsigned)(lg_first + q) < (unsigned)p.M && lg_cg * 8 + jj < p.C8;
+        MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_off[i] : kOOB, lg_soff);
+    };
+    auto run_next = [&]() __attribute__((always_inline)) {
+        if (++lg_r == 3) {
+            lg_r = 0;
+            if (++lg_cg == G) {
+                lg_cg = 0;
+                if (lg_tile == last_tile) lg_live = false;
+                else { lg_tile += tile_step; run_tile(lg_tile); }
+            }
+        }
+        run_setup();
+    };
+
+    // ---- fragment reads ---------------------------------------------------------------------------
+    // run buffer: fragment row = wave row + i*16 + (lane & 15) + s; the 16-byte chunk of k-chunk c of
+    // buffer row q sits at position c ^ (q & 7)
+    const int c0 = lane >> 4;
+    unsigned a_sh[3];                              // byte offset inside a run buffer of fragment 0 at shift s
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        a_sh[s] = (unsigned)((wm * TM + (lane & 15) + s) * 128 + ((c0 ^ (((lane & 7) + s) & 7)) << 4));
+    const unsigned z_addr = (unsigned)(ZERO_OFF + c0 * 16);
+    const int b_frag_base = B_OFF + (wn * TN + (lane & 15)) * 128 + ((c0 ^ (lane & 7)) << 4);
+    uint32_t vmask[FM];                            // tap-validity bits of this lane's FM pixels (tile being read)
+    unsigned a_eff[FM];                            // LDS address of the fragments of the step being read
+    auto tile_masks = [&](int t) __attribute__((always_inline)) {
+        const int mb = t * BM + wm * TM + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = mb + i * 16;
+            uint32_t mask = 0;
+            if (m < p.M) {
+                const int b = m / p.HoWo;
+                const int rem = m - b * p.HoWo;
+                const int y = rem / p.W;
+                const int x = rem - y * p.W;
+                const uint32_t rows = (y > 0 ? 0x007u : 0u) | 0x038u | (y < p.H - 1 ? 0x1c0u : 0u);
+                const uint32_t cols = (x > 0 ? 0x049u : 0u) | 0x092u | (x < p.W - 1 ? 0x124u : 0u);
+                mask = rows & cols;
+            }
+            vmask[i] = mask;
+        }
+    };
+    auto set_a_eff_one = [&](int buf, int r, int s, int i) __attribute__((always_inline)) {
+        const unsigned a = a_sh[s] + (unsigned)(buf * A_BUF + i * 2048);
+        a_eff[i] = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
+    };
+    auto read_x = [&](int i, int kk) -> bf16x8 {
+        return *(const __attribute__((address_space(3))) bf16x8*)(smem + (a_eff[i] ^ (unsigned)(kk * 64)));
+    };
+    auto read_w = [&](int stage, int kk, int j) -> bf16x8 {
+        return *(const __attribute__((address_space(3))) bf16x8*)(smem + stage * B_BYTES + j * 2048 +
+                                                                 (b_frag_base ^ (kk * 64)));
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- epilogue (as conv_v2: scalar bias, pixel-row order, 16-byte stores) --------------------------
+    const int q4 = lane >> 4;
+    auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t) __attribute__((always_inline)) {
+        constexpr bool HAS_RES = decltype(has_res_t)::value;
+        constexpr bool OUT_F32 = decltype(out_f32_t)::value;
+        const int m0 = tile_m * BM + wm * TM + (lane & 15);
+        const int nbase = n0 + wn * TN + q4 * 4;
+        float bv[FN][4];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int nb = n0 + wn * TN + j * 16;                // wave-uniform: bias comes through s_load
+            bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
+            if (nb < p.n_rows) {
+                f32x16 b16;
+                const unsigned long long ba = (unsigned long long)(p.bias + nb);
+                const unsigned long long bs =
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)ba);
+                asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b16) : "s"(bs) : "memory");
+                const f32x4 g0 = {b16[0], b16[1], b16[2], b16[3]}, g1 = {b16[4], b16[5], b16[6], b16[7]},
+                            g2 = {b16[8], b16[9], b16[10], b16[11]}, g3 = {b16[12], b16[13], b16[14], b16[15]};
+                const f32x4 g = q4 == 0 ? g0 : (q4 == 1 ? g1 : (q4 == 2 ? g2 : g3));
+                bv[j][0] = g[0]; bv[j][1] = g[1]; bv[j][2] = g[2]; bv[j][3] = g[3];
+            }
+        }
+        uint2 rrow[2][FN];
+        auto fetch_res_row = [&](int i, uint2 (&r)[FN]) {
+            // branch-free (clamped) addresses: a load under a divergent branch would make the compiler
+            // fall back from counted vmcnt waits to vmcnt(0), which also waits for stores
+            const int m = min(m0 + i * 16, p.M - 1);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) r[j] = *(const uint2*)(p.res + (size_t)m * p.ld_res + min(nbase + j * 16, p.N - 4));
+        };
+        if constexpr (HAS_RES) fetch_res_row(0, rrow[0]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (HAS_RES) {
+                if (i + 1 < FM) fetch_res_row(i + 1, rrow[(i + 1) & 1]);
+            }
+            const int m = m0 + i * 16;
+            float v[FN][4];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] + bv[j][r];
+                    if ((PROF & 4) == 0 && p.act) t = silu_f32(t);
+                    v[j][r] = t;
+                }
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (HAS_RES) {
+                    const uint2 rv = rrow[i & 1][j];
+                    v[j][0] += bf16_to_f32((uint16_t)(rv.x & 0xffff));
+                    v[j][1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+                    v[j][2] += bf16_to_f32((uint16_t)(rv.y & 0xffff));
+                    v[j][3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+                }
+            }
+            if constexpr ((PROF & 2) != 0) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(v[j][0]), "v"(v[j][1]), "v"(v[j][2]), "v"(v[j][3]));
+            } else if constexpr (OUT_F32) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = nbase + j * 16;
+                    if (m < p.M && n < p.N)
+                        *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                }
+            } else {
+                uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
+#pragma unroll
+                for (int j = 0; j + 1 < FN; j += 2) {
+                    unsigned a0 = pack2_bf16(v[j][0], v[j][1]), a1 = pack2_bf16(v[j][2], v[j][3]);
+                    unsigned b0 = pack2_bf16(v[j + 1][0], v[j + 1][1]), b1 = pack2_bf16(v[j + 1][2], v[j + 1][3]);
+                    auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
+                    auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
+                    if (m < p.M && n < p.N) *(uint4*)(orow + n) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+                if (FN & 1) {
+                    const int j = FN - 1;
+                    const int n = nbase + j * 16;
+                    uint2 o;
+                    o.x = pack2_bf16(v[j][0], v[j][1]);
+                    o.y = pack2_bf16(v[j][2], v[j][3]);
+                    if (m < p.M && n < p.N) *(uint2*)(orow + n) = o;
+                }
+            }
+        }
+    };
+    auto epilogue = [&](int tile_m) __attribute__((always_inline)) {
+        if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{});
+        else if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{});
+        else epilogue_t(tile_m, std::false_type{}, std::false_type{});
+    };
+
+    // ---- prologue: run (first tile, group 0, r 0) in buffer 0, weight slabs of steps 0 and 1 ----------
+    run_tile(first_tile);
+    run_setup();
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        if (i * NW + wave < A_PIECES) {
+            const int q = (i * NW + wave) * 8 + lr;
+            const bool ok = (unsigned)(lg_first + q) < (unsigned)p.M && jj < p.C8;
+            MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, ok ? q_off[i] : kOOB, lg_soff);
+        }
+    }
+    run_next();
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            if ((B_PIECES % NW) != 0 && i == B_PER - 1 && wave >= B_PIECES % NW) continue;
+            MDHIP_DMA16(b_rsrc, smem + B_OFF + st * B_BYTES + (i * NW + wave) * 1024, b_off[i], l_step * 128);
+        }
+        dma_b_done();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+    tile_masks(first_tile);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) set_a_eff_one(0, 0, 0, i);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xa[i] = read_x(i, 0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wa[j] = read_w(0, 0, j);
+
+    int c_r = 0, c_cg = 0, c_tile = first_tile, pa = 0, step = 0;
+    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if constexpr ((PROF & 1) != 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            t_acc[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if constexpr ((PROF & 1) != 0) t_prev = __builtin_amdgcn_s_memtime();
+#define MDHIP_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // a half-full last channel group (C_in mod 64 <= 32) has nothing in k 32..63: its second-half MFMAs are skipped
+    const bool tail_short = (p.C8 & 7) != 0 && (p.C8 & 7) <= 4;
+    constexpr int DMA_MAX = B_PER + A_H0, DMA_PER_G = (DMA_MAX + FN - 1) / FN;
+    for (int run = 0; run < total_runs; ++run) {
+        const bool skip_y = tail_short && c_cg == G - 1;
+        const bool tile_end = c_r == 2 && c_cg == G - 1;
+        const int n_r = c_r == 2 ? 0 : c_r + 1;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int cur = step & 1;
+            // the step being prefetched: the next tap of this run, or the first tap of the next run
+            const int ns = (s + 1) % 3;
+            const int nbuf = s == 2 ? pa ^ 1 : pa;
+            const int nr = s == 2 ? n_r : c_r;
+            if (s == 2 && tile_end) tile_masks(c_tile + tile_step);       // (masks of a tile past the stream's end are never used)
+            // ---- first half: k 0..31 of this step, while its k 32..63 fragments are read and the
+            //      fragment addresses of the next step are selected; MFMA chunk g = fragment column g ----
+#pragma unroll
+            for (int g = 0; g < FN; ++g) {
+                wb[g] = read_w(cur, 1, g);
+                if (g < FM) { xb[g] = read_x(g, 1); set_a_eff_one(nbuf, nr, ns, g); }
+                if (g == FN - 1) {
+#pragma unroll
+                    for (int i = FN; i < FM; ++i) { xb[i] = read_x(i, 1); set_a_eff_one(nbuf, nr, ns, i); }
+                }
+                MDHIP_FENCE();
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], xa[i], acc[i][g], 0, 0, 0);
+                MDHIP_FENCE();
+            }
+
+            stamp(0);
+            // everything this wave requested has landed; its reads of weight stage `cur` are complete
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stamp(1);
+            __builtin_amdgcn_s_barrier();
+            stamp(2);
+            MDHIP_FENCE();
+
+            // ---- second half: the k 0..31 fragments of the next step, MFMAs on k 32..63, and the DMA
+            //      pieces (weight slab of step+2; in steps 0 and 1 the next run) behind the MFMA chunks ----
+#pragma unroll
+            for (int g = 0; g < FN; ++g) {
+                wa[g] = read_w(cur ^ 1, 0, g);
+                if (g < FM) xa[g] = read_x(g, 0);
+                if (g == FN - 1) {
+#pragma unroll
+                    for (int i = FN; i < FM; ++i) xa[i] = read_x(i, 0);
+                }
+                MDHIP_FENCE();
+                if (!skip_y) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+                        acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], xb[i], acc[i][g], 0, 0, 0);
+                }
+                MDHIP_FENCE();
+#pragma unroll
+                for (int d = g * DMA_PER_G; d < (g + 1) * DMA_PER_G && d < DMA_MAX; ++d) {
+                    if (d < B_PER) dma_b_piece(cur, d);
+                    else if (s == 0 && d - B_PER < A_H0) dma_run_piece(pa ^ 1, d - B_PER);
+                    else if (s == 1 && A_H0 + d - B_PER < A_PER) dma_run_piece(pa ^ 1, A_H0 + d - B_PER);
+                }
+                MDHIP_FENCE();
+            }
+            dma_b_done();
+            ++step;
+            stamp(3);
+        }
+        // the run is consumed: the loader moves on; maybe the tile is complete
+        run_next();
+        pa ^= 1;
+        c_r = n_r;
+        if (n_r == 0 && ++c_cg == G) {
+            c_cg = 0;
+            epilogue(c_tile);
+            c_tile += tile_step;
+        }
+        stamp(5);
+    }
+#undef MDHIP_FENCE
+    if constexpr ((PROF & 1) != 0) {
+        if (lane == 0 && p.dbg) {
+            unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+            for (int k = 0; k < 6; ++k) d[k] = t_acc[k];
+            d[6] = (unsigned long long)step;
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------
+// configuration table
+// ---------------------------------------------------------------------------------------
+// id (local), BM, BN, waves along M, waves along N, PROF bits
+#define MDHIP_CONV5_CFGS(X) \
+    X(0, 128, 160, 2, 2, 0) \
+    X(1, 128, 80, 4, 1, 0)  \
+    X(2, 256, 160, 4, 2, 0)
+#define MDHIP_CONV5_PROF(X)  \
+    X(3, 128, 160, 2, 2, 1)  \
+    X(4, 128, 160, 2, 2, 16) \
+    X(5, 128, 160, 2, 2, 22)
+
+static const ConvCfg g_cfgs5[] = {
+#define X(id, bm, bn, wm, wn, prof)                                                                   \
+    {bm, bn, (wm) * (wn) * 64, (size_t)v5_lds_bytes(bm, bn), v5_blocks_per_cu(bm, bn, (wm) * (wn)), \
+     "v5:run" #bm "x" #bn "/" #wm "x" #wn "/" #prof},
+    MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
+#undef X
+};
+constexpr int kNumProf5 = 3;
+
+int conv5_num_cfgs() { return (int)(sizeof(g_cfgs5) / sizeof(g_cfgs5[0])) - kNumProf5; }
+const ConvCfg& conv5_cfg(int i) { return g_cfgs5[i]; }
+
+hipError_t conv5_init() {
+    hipError_t e = hipSuccess;
+#define X(id, bm, bn, wm, wn, prof)                                                              \
+    if (e == hipSuccess)                                                                       \
+        e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof>,                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs5[id].lds_bytes);
+    MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
+#undef X
+    return e;
+}
+
+bool conv5_supports(int cfg, const ConvArgs& a) {
+    if (cfg < 0 || cfg >= conv5_num_cfgs() + kNumProf5) return false;
+    return a.wgt4 != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H &&
+           a.Wo == a.W && a.C8 >= 8 && (a.N % 8) == 0 &&
+           (long long)(2 * a.W + g_cfgs5[cfg].bm + 16) * a.ld_in * 2 + 4096 < 0x7fffffffLL;
+}
+
+hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s) {
+    if (!conv5_supports(cfg, a)) return hipErrorInvalidValue;
+    const ConvCfg& c = g_cfgs5[cfg];
+    ConvArgs p = a;
+    p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;
+    p.tiles_m = (a.M + c.bm - 1) / c.bm;
+    p.tiles_per_xcd = (p.tiles_m + 7) / 8;
+    p.m_streams = std::max(1, std::min(p.tiles_per_xcd, (32 * c.blocks_per_cu) / p.tiles_n));
+    const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
+    switch (cfg) {
+#define X(id, bm, bn, wm, wn, prof)                                                               \
+    case id:                                                                                    \
+        hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        break;
+        MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
+#undef X
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mdhip

@@ -83,6 +83,12 @@ const ConvCfg& conv4_cfg(int i);
 bool conv4_supports(int cfg, const ConvArgs& a);
 hipError_t conv4_launch(int cfg, const ConvArgs& a, hipStream_t s);
 hipError_t conv4_init();
+// 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp)
+int conv5_num_cfgs();
+const ConvCfg& conv5_cfg(int i);
+bool conv5_supports(int cfg, const ConvArgs& a);
+hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s);
+hipError_t conv5_init();
 
 // ---------------------------------------------------------------------------------------
 // memory-bound helpers (misc_kernels.cpp)

@@ -147,8 +147,8 @@ def test_tile_configurations_agree_bitwise(n6):
 
 def test_row_patch_conv_matches_implicit_gemm_and_oracle():
     """
-    The row-patch direct convolution (conv_v4.cpp) on every op it supports of a wider test network
-    at 640x1280 (80x160 and 40x80 maps, 64..128 input channels incl. a half-full channel group):
+    The row-patch direct convolution (conv_v4.cpp) and the row-segment kernels (conv_v5.cpp), each on
+    every op it supports of a wider test network at 640x1280 (80x160 and 40x80 maps, 64..128 input channels incl. a half-full channel group):
     against the implicit-GEMM result (same arithmetic, different fp32 summation order) and, layer by
     layer, against the bf16-emulating oracle.
     """

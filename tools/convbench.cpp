@@ -48,6 +48,7 @@ static const Shape kShapes[] = {
     {"p32", 2, 16, 64, 80, 80, 3, 1, true},             // row-patch kernels: short tail group, N = 80
     {"p40", 2, 16, 80, 160, 160, 3, 1, false},          // 64 + 64 + 32 channels
     {"p40b", 3, 8, 40, 96, 200, 3, 1, true},            // 64 + 32 channels, ragged N
+    {"odd", 3, 19, 37, 96, 200, 3, 1, true},            // nothing divides anything: masks, ragged M and N
     {"small", 2, 24, 40, 64, 96, 3, 1, true},
     {"small1", 2, 24, 40, 64, 96, 1, 1, false},
     {"smalls2", 2, 24, 40, 64, 96, 3, 2, false},
@@ -92,6 +93,7 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "all")) { for (int j = 0; j < conv_num_cfgs(); ++j) cfgs.push_back(j); continue; }
         if (argv[i][0] == 'p') { cfgs.push_back(-1 - atoi(argv[i] + 1)); continue; }   // p0, p1: instrumented v2 variants
         if (argv[i][0] == 'r') { cfgs.push_back(-201 - atoi(argv[i] + 1)); continue; } // r0, r1: v4 developer variants
+        if (argv[i][0] == 't') { cfgs.push_back(-301 - atoi(argv[i] + 1)); continue; } // t0..: v5 developer variants
         if (argv[i][0] == 'q') { cfgs.push_back(-101 - atoi(argv[i] + 1)); continue; } // q0, q1: v3 developer variants
         cfgs.push_back(atoi(argv[i]));
     }
@@ -205,7 +207,7 @@ int main(int argc, char** argv) {
             if (ms < best) best = ms;
         }
         printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
-               cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg <= -101 ? conv3_cfg(conv3_num_cfgs() - 101 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
+               cfg <= -301 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg <= -101 ? conv3_cfg(conv3_num_cfgs() - 101 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
                bad ? "  <-- MISMATCH" : "");
         if (cfg < 0 && (cfg > -101 || cfg <= -201)) {
             // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
