@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=1280)
     ap.add_argument('--model', default='YOLOV5X6_MD')
+    ap.add_argument('--src', default=None,
+                    help='HxW of the source images (e.g. 1536x2048): the real-shape variant of SURVEY.md 8(d), '
+                         'the letterbox kernel resizes to the --size long side; not the headline configuration')
     ap.add_argument('--threshold', type=float, default=1e-5,
                     help='detection threshold handed to NMS (batch mode default of the reference)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -100,9 +103,12 @@ def main():
 
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.hip_backend import HipContext
-    from megadetector_amd.postprocess import format_detections
+    from megadetector_amd.postprocess import format_detections, letterbox_geometry
 
     B, S = args.batch, args.size
+    H0, W0 = (int(v) for v in args.src.lower().split('x')) if args.src else (S, S)
+    lb = letterbox_geometry((H0, W0), new_shape=S, stride=64, auto=True, scaleup=True)
+    Hn, Wn = lb['out_hw']                       # network input (letterboxed) shape
     yaml = getattr(yolo_yaml, args.model)
     weights = weights_io.synthetic_weights(yaml, seed=0)
     ctx = HipContext(weights, device=local_rank, dtype='bf16', max_batch=B, max_h=S, max_w=S)
@@ -115,8 +121,8 @@ def main():
     batches = []
     for i in range(n_batches):
         gen.manual_seed(1000 * rank + i)
-        batches.append(torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda', generator=gen))
-    geoms = [(S, S, S, S, 0, 0)] * B
+        batches.append(torch.randint(0, 256, (B, H0, W0, 3), dtype=torch.uint8, device='cuda', generator=gen))
+    geoms = [(H0, W0, lb['new_unpad'][1], lb['new_unpad'][0], lb['top'], lb['left'])] * B
     ptr_lists = [[int(b[i].data_ptr()) for i in range(B)] for b in batches]
     # everything is enqueued on one non-blocking stream (the legacy null stream synchronises implicitly
     # with every other blocking stream and measured ~1.5 ms per step slower)
@@ -146,18 +152,18 @@ def main():
                 dev_in[k].copy_(host_batches[i % n_batches], non_blocking=True)
                 copied[k].record(copy_s)
             comp_s.wait_event(copied[k])
-            ctx.preprocess(dev_ptrs[k], geoms, S, S, stream=compute_stream)
+            ctx.preprocess(dev_ptrs[k], geoms, Hn, Wn, stream=compute_stream)
             consumed[k].record(comp_s)
-            ctx.forward(B, S, S, stream=compute_stream)
+            ctx.forward(B, Hn, Wn, stream=compute_stream)
             ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=i % 4, stream=compute_stream)
             return
-        ctx.preprocess(ptr_lists[i % n_batches], geoms, S, S, stream=compute_stream)
-        ctx.forward(B, S, S, stream=compute_stream)
+        ctx.preprocess(ptr_lists[i % n_batches], geoms, Hn, Wn, stream=compute_stream)
+        ctx.forward(B, Hn, Wn, stream=compute_stream)
         ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=i % 4, stream=compute_stream)
 
     def collect(i):
         det, counts = ctx.nms_wait(slot=i % 4)
-        return [format_detections(det[b, :counts[b]], (S, S), (S, S, 3), (S, S, 3), args.threshold)
+        return [format_detections(det[b, :counts[b]], (Hn, Wn), (H0, W0, 3), (H0, W0, 3), args.threshold)
                 for b in range(B)]
 
     def run(n_steps):
@@ -208,18 +214,18 @@ def main():
             return (time.perf_counter() - t) / reps * 1e3
         ms = np.zeros(ctx.num_ops(), dtype=np.float64)
         if not args.lean:
-            stages['preprocess_ms'] = timed(lambda: ctx.preprocess(dev_ptrs[0] if args.host_fed else ptr_lists[0], geoms, S, S))
-            stages['forward_ms'] = timed(lambda: ctx.forward(B, S, S))
+            stages['preprocess_ms'] = timed(lambda: ctx.preprocess(dev_ptrs[0] if args.host_fed else ptr_lists[0], geoms, Hn, Wn))
+            stages['forward_ms'] = timed(lambda: ctx.forward(B, Hn, Wn))
             stages['nms_d2h_ms'] = timed(lambda: ctx.nms(B, args.threshold, 0.45, 300))
             det, cnt = ctx.nms(B, args.threshold, 0.45, 300)
             t = time.perf_counter()
             for b in range(B):
-                format_detections(det[b, :cnt[b]], (S, S), (S, S, 3), (S, S, 3), args.threshold)
+                format_detections(det[b, :cnt[b]], (Hn, Wn), (H0, W0, 3), (H0, W0, 3), args.threshold)
             stages['host_format_ms'] = (time.perf_counter() - t) * 1e3
             stages['mean_detections_per_image'] = float(np.mean(cnt))
             reps = 3
             for _ in range(reps):
-                ms += ctx.forward_timed(B, S, S)
+                ms += ctx.forward_timed(B, Hn, Wn)
             ms /= reps
         infos = ctx.op_infos()
         conv = [(o, ms[o['op']]) for o in infos if o['kind'] == 0]
@@ -239,7 +245,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get('key') == '{}:{}:{}'.format(args.model, B, S):
+                if tj.get('key') == '{}:{}:{}'.format(args.model, B, S) and not args.src:
                     traffic = tj.get('hbm_bytes_per_step')
             except Exception:
                 traffic = None
@@ -266,7 +272,7 @@ def main():
                 'ms_per_step': round(top[1][1], 3), 'avg_launch_us': round(top[1][1] / top[1][0] * 1e3, 2),
                 'flops_per_step': top[1][2], 'achieved_tflops': round(top[1][2] / (top[1][1] * 1e-3) / 1e12, 2),
                 'frac': round(top[1][2] / (top[1][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
-        if args.model == 'YOLOV5X6_MD' and S == 1280:
+        if args.model == 'YOLOV5X6_MD' and (Hn, Wn) == (1280, 1280):
             assert abs(conv_flops / B / 1e9 - GFLOP_PER_IMAGE_1280) < 0.05, conv_flops / B / 1e9
         if args.profile_out and not args.lean:
             os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)), exist_ok=True)
@@ -284,7 +290,9 @@ def main():
         total_images = world * B * args.steps
         line = {
             'metric': 'images/sec (whole node) MDv5a @1280px batch inference' +
-                      (' [host-fed: PCIe-inclusive, not the headline value]' if args.host_fed else ''),
+                      (' [host-fed: PCIe-inclusive, not the headline value]' if args.host_fed else '') +
+                      (' [real-shape variant {}x{} -> {}x{}, not the headline configuration]'.format(H0, W0, Hn, Wn)
+                       if args.src else ''),
             'value': round(total_images / elapsed, 2),
             'unit': 'images/s',
             'n_gpus': world,
@@ -297,9 +305,10 @@ def main():
             'dtype': 'bf16',
             'data': 'synthetic',
             'config': {
-                'workload': 'MDv5a topology (YOLOv5x6, nc=3, 163 convs, 831.64 GFLOP/image) bf16, '
-                            '{0}x{0} letterbox, batch {1} per GPU, uint8 RGB inputs resident in HBM, seeded '
-                            'synthetic weights (no checkpoint available offline), NMS threshold {2}'.format(S, B, args.threshold),
+                'workload': 'MDv5a topology (YOLOv5x6, nc=3, 163 convs, {3:.2f} GFLOP/image) bf16, '
+                            '{0}x{4} letterbox, batch {1} per GPU, uint8 RGB inputs resident in HBM, seeded '
+                            'synthetic weights (no checkpoint available offline), NMS threshold {2}'.format(
+                                Hn, B, args.threshold, GFLOP_PER_IMAGE_1280 * Hn * Wn / (1280.0 * 1280.0), Wn),
                 'model': args.model, 'batch_per_gpu': B, 'image_size': S,
                 'parallelism': 'image queue sharded over {} GPU(s), one process per GPU, no collectives'.format(world),
             },

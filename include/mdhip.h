@@ -181,14 +181,18 @@ int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg);
 int mdhip_cfg_is_bitwise(int cfg);
 /* human-readable name of a tile configuration ("v2:160x160/2x2", ...); "" when out of range */
 const char* mdhip_conv_cfg_name(int cfg);
-/* measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json): a conv whose GEMM
- * shape matches an entry exactly runs configuration `cfg`; everything else uses the built-in heuristic.
- * A configuration that does not support the op falls back to the heuristic choice. */
+/* measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json): a conv runs the
+ * configuration of the entry with the same layer geometry (N, K, taps, stride, residual) whose
+ * PER-IMAGE M (= m / batch = Ho*Wo) is equal or, failing that, nearest within a factor 4 (the same
+ * layer at another image shape); everything else uses the built-in heuristic.  The choice does not
+ * depend on the batch size of the call, so an image's result is bit-identical whatever batch it is
+ * part of.  A configuration that does not support the op falls back to the heuristic choice. */
 typedef struct {
-    int32_t m, n, k;        /* GEMM view: M = batch*Ho*Wo, N = C_out, K = kh*kw*C_in */
+    int32_t m, n, k;        /* GEMM view at measurement: M = batch*Ho*Wo, N = C_out, K = kh*kw*C_in */
     int32_t ntaps, stride;  /* kh*kw, conv stride */
     int32_t has_res;        /* 1 when the op adds a residual */
     int32_t cfg;
+    int32_t batch;          /* batch size the entry was measured at (<= 0: taken as 32) */
 } mdhip_tuned;
 int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n);
 /* time one op in isolation: `iters` back-to-back launches bracketed by events */

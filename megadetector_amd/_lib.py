@@ -50,7 +50,7 @@ class mdhip_op_info(C.Structure):
 
 class mdhip_tuned(C.Structure):
     _fields_ = [('m', C.c_int32), ('n', C.c_int32), ('k', C.c_int32), ('ntaps', C.c_int32),
-                ('stride', C.c_int32), ('has_res', C.c_int32), ('cfg', C.c_int32)]
+                ('stride', C.c_int32), ('has_res', C.c_int32), ('cfg', C.c_int32), ('batch', C.c_int32)]
 
 
 #: every symbol include/mdhip.h declares: name -> (restype, argtypes)

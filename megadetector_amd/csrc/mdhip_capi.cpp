@@ -100,7 +100,7 @@ struct mdhip_ctx {
     int last_n = 0, last_h = 0, last_w = 0;
     std::string err;
     std::vector<hipEvent_t> events;
-    std::vector<mdhip_tuned> tuned;   // measured tile choices (tools/autotune.py), exact-shape matches only
+    std::vector<mdhip_tuned> tuned;   // measured tile choices (tools/autotune.py)
     // optional event pair around every mdhip_forward (bench.py's live roofline measurement)
     static constexpr int kFwdRing = 64;
     bool time_forward = false;
@@ -598,13 +598,25 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             bool from_table = false;
             if (cfg < 0) {
                 const PackedConv& pc = ctx->packed[op.pc];
-                for (const mdhip_tuned& t : ctx->tuned)
-                    if (t.m == a.M && t.n == pc.c_out && t.k == pc.k_real && t.ntaps == a.ntaps && t.stride == a.stride &&
-                        t.has_res == (op.has_res ? 1 : 0)) {
+                // The entry of the same layer geometry (N, K, taps, stride, residual) whose per-image M is
+                // equal or nearest within 4x (the same layer at another image shape, e.g. 960x1280 instead
+                // of 1280x1280), if that kernel takes this op.  Per image, not per call: the kernel family
+                // (= fp32 summation order) of an op must not depend on the batch size, or an image's
+                // result would depend on the batch it travels in.
+                double best = 1e30;
+                const double m_img = (double)a.M / n;
+                for (const mdhip_tuned& t : ctx->tuned) {
+                    if (t.n != pc.c_out || t.k != pc.k_real || t.ntaps != a.ntaps || t.stride != a.stride ||
+                        t.has_res != (op.has_res ? 1 : 0) || t.m <= 0)
+                        continue;
+                    const double t_img = (double)t.m / (t.batch > 0 ? t.batch : 32);
+                    const double r = t_img > m_img ? t_img / m_img : m_img / t_img;
+                    if (r < best && r <= 4.0 && conv_supports(t.cfg, a)) {
+                        best = r;
                         cfg = t.cfg;
                         from_table = true;
-                        break;
                     }
+                }
             }
             if (cfg < 0) cfg = choose_cfg(a.M, a.n_rows);
             hipError_t le = conv_launch(cfg, a, s);

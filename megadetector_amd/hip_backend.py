@@ -95,6 +95,7 @@ class HipContext:
             arr[i].m, arr[i].n, arr[i].k = int(e['m']), int(e['n']), int(e['k'])
             arr[i].ntaps, arr[i].stride = int(e['ntaps']), int(e['stride'])
             arr[i].has_res, arr[i].cfg = int(e['has_res']), int(e['cfg'])
+            arr[i].batch = int(e.get('batch', 32))
         self._check(self.lib.mdhip_set_tuned(self.h, arr, len(entries)), 'mdhip_set_tuned')
         return len(entries)
 

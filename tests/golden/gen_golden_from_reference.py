@@ -14,7 +14,7 @@ What is exercised from the reference itself:
     torchvision.  cv2 / humanfriendly / jsonpickle are stubbed as empty modules: nothing
     on this path touches them.
 
-Run:  python tools/gen_golden_from_reference.py
+Run:  python tests/golden/gen_golden_from_reference.py
 """
 
 import json
@@ -25,7 +25,7 @@ import types
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 sys.path.insert(0, '/root/reference')
 

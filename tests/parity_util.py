@@ -1,4 +1,4 @@
-"""Helpers shared by the GPU parity tests, tools/gpu_diag.py and bench.py's checker leg."""
+"""Helpers shared by the GPU parity tests, tests/gpu_diag.py and bench.py's checker leg."""
 
 import numpy as np
 import torch

@@ -18,6 +18,7 @@ Tolerances (stated once, used below):
 """
 
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -210,6 +211,35 @@ def test_batch_composition_invariance(n6):
         np.testing.assert_array_equal(ctx.read_predictions(1, 256, 256)[0], full[i])
 
 
+def test_batch_composition_invariance_with_measured_table():
+    """The shipped tile table (megadetector_amd/tuned_cfgs.json, measured at batch 32 / 1280x1280) applied to
+    the MDv5 topology at 640x640 and 384x640: kernels of both summation-order families are in use, and an
+    image's predictions are bit-identical whether it travels alone or in a batch (the table is looked up
+    per image, never per call)."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    ctx = HipContext(W, device=0, max_batch=3, max_h=640, max_w=640)
+    try:
+        for (hh, ww) in ((640, 640), (384, 640)):
+            imgs = PU.structured_images(3, hh, ww, seed=41)
+            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            ctx.forward(3, hh, ww)
+            full = ctx.read_predictions(3, hh, ww).copy()
+            cfgs3 = [o['cfg'] for o in ctx.op_infos() if o['kind'] == 0]
+            if (hh, ww) == (640, 640):
+                assert any(not ctx.cfg_is_bitwise(c) for c in cfgs3), 'the table selects no row-segment/row-patch kernel'
+                assert any(ctx.cfg_is_bitwise(c) for c in cfgs3)
+            for i in (0, 2):
+                ctx.preprocess([imgs[i]], _identity_geoms([imgs[i]]), hh, ww)
+                ctx.forward(1, hh, ww)
+                cfgs1 = [o['cfg'] for o in ctx.op_infos() if o['kind'] == 0]
+                assert [ctx.cfg_is_bitwise(c) for c in cfgs1] == [ctx.cfg_is_bitwise(c) for c in cfgs3]
+                np.testing.assert_array_equal(ctx.read_predictions(1, hh, ww)[0], full[i])
+    finally:
+        ctx.close()
+
+
 # ---------------------------------------------------------------------------------------
 # NMS: bit-exact against the reference fixtures and the oracle
 # ---------------------------------------------------------------------------------------
@@ -254,6 +284,22 @@ def test_nms_matches_oracle_order_exact(nms_ctx, seed, n, a, ct):
     for i in range(n):
         assert counts[i] == ref[i].shape[0]
         np.testing.assert_array_equal(out[i, :counts[i]], ref[i].numpy())
+
+
+@pytest.mark.parametrize('q', [0.99, 0.90])
+def test_nms_stress_input_full_size_exact(nms_ctx, q):
+    """SURVEY.md 8(d)'s NMS stress tensor (tools/nms_bench.py: 102000 anchors, obj ~ Beta(0.05, 1), 50 box
+    clusters) at thresholds that let 1 % / 10 % of the anchors through: exact against the oracle."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from nms_bench import stress_predictions
+    ctx = nms_ctx
+    a = ctx.num_anchors(1280, 1280)
+    pred = stress_predictions(1, a, seed=0)
+    thr = float(np.quantile(pred[..., 4] * pred[..., 5:8].max(-1), q))
+    out, counts = ctx.nms_on(pred, thr, 0.45, 300)
+    ref = O.nms(torch.from_numpy(pred), conf_thres=thr, iou_thres=0.45, max_det=300)[0].numpy()
+    assert counts[0] == ref.shape[0] > 0
+    np.testing.assert_array_equal(out[0, :counts[0]], ref)
 
 
 def test_nms_properties_full_size(nms_ctx):

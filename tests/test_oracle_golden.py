@@ -1,7 +1,7 @@
 """
 Pins the oracle (oracle/) against every golden vector / known-answer test the reference
 tree holds for this path, and against fixtures generated from the reference's own code
-(tools/gen_golden_from_reference.py).
+(tests/golden/gen_golden_from_reference.py).
 """
 
 import json

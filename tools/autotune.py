@@ -2,7 +2,7 @@
 """
 Measures every implicit-GEMM tile configuration on every conv op of a model at a given
 (batch, size) on the GPU and records the fastest per GEMM shape.  Output (json):
-  { "entries": [ {"m","n","k","ntaps","stride","has_res","cfg","ms","tflops"}, ... ] }
+  { "entries": [ {"m","n","k","ntaps","stride","has_res","cfg","batch","ms","tflops"}, ... ] }
       -> megadetector_amd/tuned_cfgs.json (loaded by HipContext, matched on the exact shape)
 plus a human-readable table (per op: ms and TFLOP/s per configuration).
 
@@ -66,7 +66,7 @@ def main():
         b = int(np.argmin(ms))
         tf = [o['flops'] / (t * 1e-3) / 1e12 if np.isfinite(t) else 0.0 for t in ms]
         entries[sig] = dict(m=sig[0], n=sig[1], k=sig[2], ntaps=sig[3], stride=sig[4], has_res=sig[5], cfg=b,
-                            ms=round(ms[b], 5), tflops=round(tf[b], 1))
+                            batch=B, ms=round(ms[b], 5), tflops=round(tf[b], 1))
         lines.append('{:34s} M={:8d} N={:5d} K={:6d} default={:2d} best={:2d} {:8.3f} ms {:7.1f} TF/s | '.format(
             o['name'], o['m'], o['n'], o['k'], o['cfg'], b, ms[b], tf[b]) +
             ' '.join('{:6.1f}'.format(t) for t in tf))

@@ -12,7 +12,7 @@ echo "== rocminfo ==" > gpurun_out/env.log
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "test" ]; then
   timeout 900 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
-  timeout 300 python tools/gpu_diag.py YOLOV5N6_TEST 256 2 > gpurun_out/diag_n6.log 2>&1
+  timeout 300 python tests/gpu_diag.py YOLOV5N6_TEST 256 2 > gpurun_out/diag_n6.log 2>&1
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "tune" ]; then
   timeout 600 python tools/autotune.py --out gpurun_out/tuned_cfgs.json > gpurun_out/autotune.log 2>&1
