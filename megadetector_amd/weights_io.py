@@ -127,9 +127,17 @@ class _CheckpointUnpickler(pickle.Unpickler):
     the yolov5 package, so `models.yolo.DetectionModel`, `models.common.Conv` ... unpickle
     without that package (reference pytorch_detector.py:950-957 needs them importable).
     """
-    _SAFE_PREFIXES = ('torch', 'collections', 'numpy', 'builtins', '_codecs', 'pathlib')
+    _SAFE_PREFIXES = ('torch', 'collections', 'numpy', '_codecs', 'pathlib')
+    # plain data types only: `builtins` also holds eval / exec / getattr / __import__
+    _SAFE_BUILTINS = ('set', 'frozenset', 'list', 'dict', 'tuple', 'slice', 'range', 'complex', 'int', 'float',
+                      'bool', 'str', 'bytes', 'bytearray', 'object')
 
     def find_class(self, module, name):
+        if module in ('builtins', '__builtin__'):          # '__builtin__': protocol-2 pickles (torch.save default)
+            if name in self._SAFE_BUILTINS:
+                import builtins
+                return getattr(builtins, name)
+            raise pickle.UnpicklingError('refusing to unpickle {}.{}'.format(module, name))
         if module.split('.')[0] in self._SAFE_PREFIXES:
             return super().find_class(module, name)
         if module.split('.')[0] in ('models', 'utils', 'yolov5', 'ultralytics', '__main__'):

@@ -1,0 +1,77 @@
+"""
+The checkpoint reader (megadetector_amd.weights_io.load_checkpoint) against a checkpoint with the pickle
+layout of md_v5a.0.0.pt -- whole fp16 `models.yolo.DetectionModel` module, BatchNorm not fused -- written
+by an independent torch.nn implementation of the architecture (tests/fake_yolov5.py).  The reference
+loads such a file with the yolov5 package importable and calls `.float().fuse().eval()`
+(pytorch_detector.py:929-957); here the package is absent when the file is read.
+
+What is pinned: (1) the stub unpickler resolves every class of the file; (2) BatchNorm folding and the
+state-dict name mapping: the oracle's forward on the loaded weights equals the nn.Module's own eval-mode
+forward; (3) anchors, strides, class names.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fake_yolov5 as FY  # noqa: E402
+import parity_util as PU  # noqa: E402
+
+from megadetector_amd import weights_io, yolo_yaml  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def checkpoint(tmp_path_factory):
+    model = FY.build_model(yolo_yaml.YOLOV5N6_TEST, seed=3)
+    path = str(tmp_path_factory.mktemp('ckpt') / 'fake_md_v5.pt')
+    FY.save_checkpoint(model, path)
+    ref_model = FY.build_model(yolo_yaml.YOLOV5N6_TEST, seed=3).half().float()      # what .float() of the file holds
+    x = torch.rand(2, 3, 128, 192, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref_pred = ref_model(x)
+    FY.uninstall()          # from here on `models.*` is not importable, as in a MegaDetector-free process
+    return path, x, ref_pred, ref_model
+
+
+def test_checkpoint_reads_without_the_yolov5_package(checkpoint):
+    path, x, ref_pred, ref_model = checkpoint
+    assert 'models' not in sys.modules and 'models.yolo' not in sys.modules
+    W = weights_io.load_checkpoint(path)
+    assert 'models.yolo' not in sys.modules
+    assert W.yaml['nc'] == 3 and W.names == {0: 'animal', 1: 'person', 2: 'vehicle'}
+    assert W.max_stride == 64
+    det = [k for k in W.weights if k.endswith('.anchors')]
+    assert len(det) == 1
+    want = np.asarray(yolo_yaml.YOLOV5N6_TEST['anchors'], np.float32).reshape(4, 3, 2) / \
+        np.asarray([8, 16, 32, 64], np.float32).reshape(4, 1, 1)
+    np.testing.assert_allclose(W.weights[det[0]], want, rtol=1e-3)      # stored in fp16 in the file
+    # every conv of the topology has a folded weight and bias of the right shape
+    n_convs = sum(1 for k in W.weights if k.endswith('.weight'))
+    assert n_convs == sum(1 for m in ref_model.modules() if isinstance(m, torch.nn.Conv2d))
+
+
+def test_folded_weights_reproduce_the_module_forward(checkpoint):
+    path, x, ref_pred, _ = checkpoint
+    W = weights_io.load_checkpoint(path)
+    pred, _ = PU.oracle_forward(W, x, emulate_bf16=False)
+    assert pred.shape == ref_pred.shape
+    # same arithmetic up to the BatchNorm fold (fp32 re-association): tight tolerance
+    np.testing.assert_allclose(pred[..., :4].numpy(), ref_pred[..., :4].numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(pred[..., 4:].numpy(), ref_pred[..., 4:].numpy(), rtol=0, atol=5e-4)
+
+
+def test_refuses_foreign_classes(tmp_path):
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+    p = str(tmp_path / 'evil.pt')
+    torch.save({'model': Evil()}, p)
+    with pytest.raises((pickle.UnpicklingError, RuntimeError, Exception)) as ei:
+        weights_io.load_checkpoint(p)
+    assert 'refusing' in str(ei.value) or 'posix' in str(ei.value) or 'nt' in str(ei.value)

@@ -409,6 +409,41 @@ def test_detector_end_to_end_vs_oracle():
     assert res[0]['detections'] is not None
 
 
+def test_checkpoint_file_through_load_detector(tmp_path):
+    """
+    A .pt file with the pickle layout of md_v5a.0.0.pt (tests/fake_yolov5.py: whole fp16 module, BatchNorm
+    not fused, `models.*` classes that are not importable here) through the reference's entry point
+    `run_detector.load_detector(path)`: the HIP predictions against the file's own nn.Module forward
+    (fp32, = what the reference computes from this file), and detections == the reference's
+    post-processing statements applied to the HIP predictions.
+    """
+    import fake_yolov5 as FY
+    from megadetector_amd import run_detector, yolo_yaml
+    model = FY.build_model(yolo_yaml.YOLOV5N6_TEST, seed=5)
+    path = str(tmp_path / 'md_fake.pt')
+    FY.save_checkpoint(model, path)
+    ref_model = model.half().float()
+    imgs = PU.structured_images(2, 256, 320, seed=51)
+    x, infos = PU.oracle_input(imgs, 320, 64)
+    with torch.no_grad():
+        ref_pred = ref_model(x).numpy()
+    FY.uninstall()
+    det = run_detector.load_detector(path, detector_options={'batch_size': 2, 'max_image_size': 320})
+    det.default_image_size = 320
+    res = det.generate_detections_one_batch(imgs, ['a.jpg', 'b.jpg'], detection_threshold=1e-5)
+    assert all('failure' not in r for r in res), res
+    h, w = x.shape[2:]
+    got = det._ctx.read_predictions(2, h, w)
+    assert got.shape == ref_pred.shape
+    e_box = PU.rel_err(got[..., :4], ref_pred[..., :4])
+    e_conf = float(np.abs(got[..., 4:] - ref_pred[..., 4:]).max())
+    assert e_box[0] < 5e-2 and e_box[1] < 1e-2 and e_conf < E2E_CONF_TOL_FP32_ORACLE, (e_box, e_conf)
+    ref_same = PU.oracle_detections(torch.from_numpy(got), infos, (h, w), 1e-5)
+    for r, q in zip(res, ref_same):
+        assert r['detections'] == q['detections']
+    assert any(len(r['detections']) > 0 for r in res)
+
+
 # ---------------------------------------------------------------------------------------
 # the batch driver on the real HIP detector: orchestration modes, JSON, failures
 # ---------------------------------------------------------------------------------------
