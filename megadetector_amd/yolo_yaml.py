@@ -126,3 +126,7 @@ YOLOV5N6_TEST = make_yaml(0.33, 0.25, nc=3, p6=True)
 #: wider small P6 network (hidden widths 64..256 at strides 8 and 16): exercises the kernels that need
 #: at least 64 input channels (row-patch 3x3) in the tests
 YOLOV5S6_TEST = make_yaml(0.33, 0.50, nc=3, p6=True)
+
+#: small P5 (3 heads, stride 32) network with 5 classes: the non-P6 family members (MDv1000-spruce is a
+#: YOLOv5s) and a class count other than 3, in the tests
+YOLOV5N_P5_TEST = make_yaml(0.33, 0.25, nc=5, p6=False)

@@ -109,6 +109,48 @@ def test_every_layer_matches_bf16_oracle(n6):
     assert np.abs(pred[..., 4:] - pred_ref[..., 4:].numpy()).max() < 2e-2
 
 
+def test_p5_family_member_with_other_class_count():
+    """
+    SURVEY.md 8(f) N4: the same kernels on a P5 network (3 Detect levels, max stride 32, as MDv1000-spruce =
+    YOLOv5s) with nc = 5 (no = 10, Detect N = 30) at a non-square 320x224 input: every layer against the
+    bf16-emulating oracle, the decoded predictions, and NMS bit-exact on those predictions.
+    """
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5N_P5_TEST, seed=2)
+    assert W.max_stride == 32
+    ctx = HipContext(W, device=0, max_batch=3, max_h=320, max_w=320)
+    try:
+        hh, ww = 320, 224
+        imgs = PU.structured_images(3, hh, ww, seed=15)
+        ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+        ctx.forward(3, hh, ww)
+        x, _ = PU.oracle_input(imgs, 320, 32)
+        assert tuple(x.shape[2:]) == (hh, ww)
+        keep = {}
+        pred_ref, _ = PU.oracle_forward(W, x, emulate_bf16=True, keep=keep)
+        bad = []
+        for i in sorted(keep):
+            e = PU.rel_err(ctx.read_layer(i, 3), keep[i].numpy())
+            if e[0] > LAYER_MAX_TOL or e[1] > LAYER_MEAN_TOL:
+                bad.append((i,) + e)
+        assert not bad, bad
+        pred = ctx.read_predictions(3, hh, ww)
+        assert pred.shape == tuple(pred_ref.shape) == (3, 3 * (40 * 28 + 20 * 14 + 10 * 7), 10)
+        emax, emean = PU.rel_err(pred[..., :4], pred_ref[..., :4].numpy())
+        assert emax < 3e-2 and emean < 8e-3
+        assert np.abs(pred[..., 4:] - pred_ref[..., 4:].numpy()).max() < 2e-2
+        out, counts = ctx.nms(3, 1e-5, 0.45, 300)
+        ref = O.nms(torch.from_numpy(pred), conf_thres=1e-5, iou_thres=0.45, max_det=300)
+        for i in range(3):
+            assert counts[i] == ref[i].shape[0]
+            np.testing.assert_array_equal(out[i, :counts[i]], ref[i].numpy())
+        assert counts.sum() > 0
+        assert set(np.unique(out[0, :counts[0], 5]).astype(int)) <= set(range(5))
+    finally:
+        ctx.close()
+
+
 def test_tile_configurations_agree_bitwise(n6):
     """
     Every implicit-GEMM tile configuration accumulates K in the same order: outputs must be
