@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=1280)
     ap.add_argument('--model', default='YOLOV5X6_MD')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'],
+                    help='storage type of activations and weights (bf16 = the BASELINE.json configuration)')
     ap.add_argument('--src', default=None,
                     help='HxW of the source images (e.g. 1536x2048): the real-shape variant of SURVEY.md 8(d), '
                          'the letterbox kernel resizes to the --size long side; not the headline configuration')
@@ -111,7 +113,7 @@ def main():
     Hn, Wn = lb['out_hw']                       # network input (letterboxed) shape
     yaml = getattr(yolo_yaml, args.model)
     weights = weights_io.synthetic_weights(yaml, seed=0)
-    ctx = HipContext(weights, device=local_rank, dtype='bf16', max_batch=B, max_h=S, max_w=S)
+    ctx = HipContext(weights, device=local_rank, dtype=args.dtype, max_batch=B, max_h=S, max_w=S)
 
     # measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json) are loaded by HipContext
 
@@ -302,10 +304,10 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'bf16',
+            'dtype': args.dtype,
             'data': 'synthetic',
             'config': {
-                'workload': 'MDv5a topology (YOLOv5x6, nc=3, 163 convs, {3:.2f} GFLOP/image) bf16, '
+                'workload': 'MDv5a topology (YOLOv5x6, nc=3, 163 convs, {3:.2f} GFLOP/image) ' + args.dtype + ', '
                             '{0}x{4} letterbox, batch {1} per GPU, uint8 RGB inputs resident in HBM, seeded '
                             'synthetic weights (no checkpoint available offline), NMS threshold {2}'.format(
                                 Hn, B, args.threshold, GFLOP_PER_IMAGE_1280 * Hn * Wn / (1280.0 * 1280.0), Wn),

@@ -36,6 +36,8 @@ extern "C" {
 /* arithmetic type of the conv stack */
 #define MDHIP_DTYPE_BF16 0
 #define MDHIP_DTYPE_FP8  1      /* reserved (BASELINE.json configs[4]); not implemented yet */
+#define MDHIP_DTYPE_FP16 2      /* fp16 storage of activations and weights (fp32 accumulate): same MFMA rate as
+                                 * bf16, 3 more mantissa bits -- the accuracy mode */
 
 /* module kinds of a YOLOv5 model description (yolov5 models/yolo.py:parse_model rows) */
 #define MDHIP_CONV      0

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'libmdhip.so')
 MDHIP_OK = 0
 MDHIP_DTYPE_BF16 = 0
 MDHIP_DTYPE_FP8 = 1
+MDHIP_DTYPE_FP16 = 2
 
 
 class mdhip_conv(C.Structure):

@@ -36,8 +36,8 @@
 #include "mdhip_internal.h"
 
 namespace mdhip {
+namespace MDHIP_ST {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -48,11 +48,9 @@ typedef __attribute__((address_space(3))) char lds_char;
 #define MDHIP_BLDS16(rsrc, lptr, voff, soff) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr), 16, (voff), (soff), 0, 0)
 
-constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records
-constexpr int kNumRecords = 0x7fffffff;
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records
+[[maybe_unused]] constexpr int kNumRecords = 0x7fffffff;
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 // SiLU = x * sigmoid(x): v_mul, v_exp, v_add, v_rcp, v_mul (each <= 1 ulp: far inside the bf16
 // rounding that follows)
@@ -61,11 +59,6 @@ __device__ __forceinline__ float silu_f32(float x) {
 }
 
 // two fp32 -> packed bf16, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
-    const f32x2_t v = {a, b};
-    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
-    return *(const uint32_t*)&r;
-}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -287,10 +280,10 @@ conv_igemm_kernel(const ConvArgs p) {
                     const int n = n0 + nl0 + j * 16;
                     if (m_ok && n < p.N) {
                         const uint2 rv = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
-                        v[j][0] += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                        v[j][1] += bf16_to_f32((uint16_t)(rv.x >> 16));
-                        v[j][2] += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                        v[j][3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+                        v[j][0] += st_unpack((uint16_t)(rv.x & 0xffff));
+                        v[j][1] += st_unpack((uint16_t)(rv.x >> 16));
+                        v[j][2] += st_unpack((uint16_t)(rv.y & 0xffff));
+                        v[j][3] += st_unpack((uint16_t)(rv.y >> 16));
                     }
                 }
             }
@@ -305,8 +298,8 @@ conv_igemm_kernel(const ConvArgs p) {
                 uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
-                    const unsigned a0 = pack2_bf16(v[j][0], v[j][1]), a1 = pack2_bf16(v[j][2], v[j][3]);
-                    const unsigned b0 = pack2_bf16(v[j + 1][0], v[j + 1][1]), b1 = pack2_bf16(v[j + 1][2], v[j + 1][3]);
+                    const unsigned a0 = st_pack2(v[j][0], v[j][1]), a1 = st_pack2(v[j][2], v[j][3]);
+                    const unsigned b0 = st_pack2(v[j + 1][0], v[j + 1][1]), b1 = st_pack2(v[j + 1][2], v[j + 1][3]);
                     const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     const auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
@@ -319,8 +312,8 @@ conv_igemm_kernel(const ConvArgs p) {
                     const int j = FN - 1;
                     const int n = n0 + nl0 + j * 16;
                     uint2 o;
-                    o.x = pack2_bf16(v[j][0], v[j][1]);
-                    o.y = pack2_bf16(v[j][2], v[j][3]);
+                    o.x = st_pack2(v[j][0], v[j][1]);
+                    o.y = st_pack2(v[j][2], v[j][3]);
                     if (m_ok && n < p.N) *(uint2*)(orow + n) = o;
                 }
             }
@@ -328,22 +321,22 @@ conv_igemm_kernel(const ConvArgs p) {
     };
 
     // ---- software pipeline over (tile, slab) steps ----------------------------------------
-    auto load_frags = [&](bf16x8 (&xf)[FM], bf16x8 (&wf)[FN], int slot, int kk) {
+    auto load_frags = [&](frag8_t (&xf)[FM], frag8_t (&wf)[FN], int slot, int kk) {
         const lds_char* sbase = smem + slot * STAGE;
         const int choff = frag_ch0 ^ (kk * 64);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
-            xf[i] = *(const __attribute__((address_space(3))) bf16x8*)(sbase + a_frag_base + i * 2048 + choff);
+            xf[i] = *(const __attribute__((address_space(3))) frag8_t*)(sbase + a_frag_base + i * 2048 + choff);
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-            wf[j] = *(const __attribute__((address_space(3))) bf16x8*)(sbase + b_frag_base + j * 2048 + choff);
+            wf[j] = *(const __attribute__((address_space(3))) frag8_t*)(sbase + b_frag_base + j * 2048 + choff);
     };
-    auto mfma_block = [&](const bf16x8 (&xf)[FM], const bf16x8 (&wf)[FN]) {
+    auto mfma_block = [&](const frag8_t (&xf)[FM], const frag8_t (&wf)[FN]) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = MDHIP_MFMA(wf[j], xf[i], acc[i][j]);
     };
 
     int issued = 0;
@@ -356,7 +349,7 @@ conv_igemm_kernel(const ConvArgs p) {
     int c_kt = 0, c_tile = first_tile;
 
     if constexpr (FP) {
-        bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+        frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
         if (NS - 2 < total_steps) wait_vmcnt<(NS - 2) * LPS>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -389,7 +382,7 @@ conv_igemm_kernel(const ConvArgs p) {
             if (issued < total_steps) { issue(nxt); ++issued; }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 xf[FM], wf[FN];
+                frag8_t xf[FM], wf[FN];
                 load_frags(xf, wf, cur, kk);
                 mfma_block(xf, wf);
             }
@@ -524,4 +517,5 @@ hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+}  // namespace MDHIP_ST
 }  // namespace mdhip

@@ -31,26 +31,19 @@
 #include "mdhip_internal.h"
 
 namespace mdhip {
+namespace MDHIP_ST {
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) char lds_char;
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records: the lane reads zeros
-constexpr int kNumRecords = 0x7fffffff;
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records: the lane reads zeros
+[[maybe_unused]] constexpr int kNumRecords = 0x7fffffff;
 
 __device__ __forceinline__ float silu_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
-    const f32x2_t v = {a, b};
-    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
-    return *(const uint32_t*)&r;
 }
 
 constexpr int v2_lds_bytes(int bm, int bn) { return 2 * (bm + bn) * 128; }
@@ -216,14 +209,14 @@ conv_v2_kernel(const ConvArgs p) {
     const int frag_ch0 = (((lane >> 4) ^ (lane & 7)) * 16);      // k 0..31 ; k 32..63 is ^ 64
     const int a_frag_base = (wm * TM) * 128 + frag_row_off;
     const int b_frag_base = A_BYTES + (wn * TN) * 128 + frag_row_off;
-    auto read_x = [&](int buf, int kk, int i) -> bf16x8 {
-        if constexpr ((PROF & 32) != 0) { bf16x8 z = {(short)(lane + i), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(z)); return z; }
-        return *(const __attribute__((address_space(3))) bf16x8*)(smem + buf * STAGE + a_frag_base + i * 2048 +
+    auto read_x = [&](int buf, int kk, int i) -> frag8_t {
+        if constexpr ((PROF & 32) != 0) return frag_dummy(lane + i);
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + buf * STAGE + a_frag_base + i * 2048 +
                                                                  (frag_ch0 ^ (kk * 64)));
     };
-    auto read_w = [&](int buf, int kk, int j) -> bf16x8 {
-        if constexpr ((PROF & 32) != 0) { bf16x8 z = {(short)(lane + j), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(z)); return z; }
-        return *(const __attribute__((address_space(3))) bf16x8*)(smem + buf * STAGE + b_frag_base + j * 2048 +
+    auto read_w = [&](int buf, int kk, int j) -> frag8_t {
+        if constexpr ((PROF & 32) != 0) return frag_dummy(lane + j);
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + buf * STAGE + b_frag_base + j * 2048 +
                                                                  (frag_ch0 ^ (kk * 64)));
     };
 
@@ -244,17 +237,6 @@ conv_v2_kernel(const ConvArgs p) {
         constexpr bool OUT_F32 = decltype(out_f32_t)::value;
         const int m0 = tile_m * BM + wm * TM + (lane & 15);
         const int nbase = n0 + wn * TN + q4 * 4;
-        uint2 rbuf[2][FM];
-        auto fetch_res = [&](int j, uint2 (&r)[FM]) {
-            // branch-free (clamped) addresses: a load under a divergent branch would make the
-            // compiler fall back from counted vmcnt waits to vmcnt(0), which also waits for stores
-            const int n = min(nbase + j * 16, p.N - 4);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = min(m0 + i * 16, p.M - 1);
-                r[i] = *(const uint2*)(p.res + (size_t)m * p.ld_res + n);
-            }
-        };
         // bias of all fragment columns first (scalar loads), then pixel-row by pixel-row so that the
         // stores that complete one cache line are issued back to back
         float bv[FN][4];
@@ -300,10 +282,10 @@ conv_v2_kernel(const ConvArgs p) {
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (HAS_RES) {
                     const uint2 rv = rrow[i & 1][j];
-                    v[j][0] += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                    v[j][1] += bf16_to_f32((uint16_t)(rv.x >> 16));
-                    v[j][2] += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                    v[j][3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+                    v[j][0] += st_unpack((uint16_t)(rv.x & 0xffff));
+                    v[j][1] += st_unpack((uint16_t)(rv.x >> 16));
+                    v[j][2] += st_unpack((uint16_t)(rv.y & 0xffff));
+                    v[j][3] += st_unpack((uint16_t)(rv.y >> 16));
                 }
             }
             if constexpr ((PROF & 2) != 0) {
@@ -323,8 +305,8 @@ conv_v2_kernel(const ConvArgs p) {
                 uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
-                    unsigned a0 = pack2_bf16(v[j][0], v[j][1]), a1 = pack2_bf16(v[j][2], v[j][3]);
-                    unsigned b0 = pack2_bf16(v[j + 1][0], v[j + 1][1]), b1 = pack2_bf16(v[j + 1][2], v[j + 1][3]);
+                    unsigned a0 = st_pack2(v[j][0], v[j][1]), a1 = st_pack2(v[j][2], v[j][3]);
+                    unsigned b0 = st_pack2(v[j + 1][0], v[j + 1][1]), b1 = st_pack2(v[j + 1][2], v[j + 1][3]);
                     auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                     auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
@@ -337,8 +319,8 @@ conv_v2_kernel(const ConvArgs p) {
                     const int j = FN - 1;
                     const int n = nbase + j * 16;
                     uint2 o;
-                    o.x = pack2_bf16(v[j][0], v[j][1]);
-                    o.y = pack2_bf16(v[j][2], v[j][3]);
+                    o.x = st_pack2(v[j][0], v[j][1]);
+                    o.y = st_pack2(v[j][2], v[j][3]);
                     if (m < p.M && n < p.N) *(uint2*)(orow + n) = o;
                 }
             }
@@ -367,7 +349,7 @@ conv_v2_kernel(const ConvArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+    frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) xa[i] = read_x(0, 0, i);
 #pragma unroll
@@ -403,7 +385,7 @@ conv_v2_kernel(const ConvArgs p) {
             if constexpr ((PROF & 64) == 0) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], xa[i], acc[i][g], 0, 0, 0);
+                    acc[i][g] = MDHIP_MFMA(wa[g], xa[i], acc[i][g]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -430,7 +412,7 @@ conv_v2_kernel(const ConvArgs p) {
             if constexpr ((PROF & 64) == 0) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], xb[i], acc[i][g], 0, 0, 0);
+                    acc[i][g] = MDHIP_MFMA(wb[g], xb[i], acc[i][g]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -550,4 +532,5 @@ hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+}  // namespace MDHIP_ST
 }  // namespace mdhip

@@ -28,28 +28,21 @@
 #include "mdhip_internal.h"
 
 namespace mdhip {
+namespace MDHIP_ST {
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) char lds_char;
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records: reads zeros / write dropped
-constexpr int kNumRecords = 0x7fffffff;
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;        // >= every descriptor's num_records: reads zeros / write dropped
+[[maybe_unused]] constexpr int kNumRecords = 0x7fffffff;
 
 __device__ __forceinline__ float silu_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
-    const f32x2_t v = {a, b};
-    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
-    return *(const uint32_t*)&r;
 }
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm0() {
@@ -233,13 +226,13 @@ conv_v3_kernel(const ConvArgs p) {
     const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ (3 * ((lane >> 3) & 1))) * 16);
     const int a_frag_base = (wm * TM) * 64 + frag_off;
     const int b_frag_base = A_BYTES + (wn * TN) * 64 + frag_off;
-    auto read_x = [&](int st, int i) __attribute__((always_inline)) -> bf16x8 {
-        if constexpr ((PROF & 32) != 0) { bf16x8 z = {(short)(lane + i), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(z)); return z; }
-        return *(const __attribute__((address_space(3))) bf16x8*)(smem + st * STAGE + a_frag_base + i * 1024);
+    auto read_x = [&](int st, int i) __attribute__((always_inline)) -> frag8_t {
+        if constexpr ((PROF & 32) != 0) return frag_dummy(lane + i);
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + st * STAGE + a_frag_base + i * 1024);
     };
-    auto read_w = [&](int st, int j) __attribute__((always_inline)) -> bf16x8 {
-        if constexpr ((PROF & 32) != 0) { bf16x8 z = {(short)(lane + j), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(z)); return z; }
-        return *(const __attribute__((address_space(3))) bf16x8*)(smem + st * STAGE + b_frag_base + j * 1024);
+    auto read_w = [&](int st, int j) __attribute__((always_inline)) -> frag8_t {
+        if constexpr ((PROF & 32) != 0) return frag_dummy(lane + j);
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + st * STAGE + b_frag_base + j * 1024);
     };
 
     f32x4 acc[FM][FN];
@@ -304,10 +297,10 @@ conv_v3_kernel(const ConvArgs p) {
                 }
                 if constexpr (HAS_RES) {
                     const uint2 rv = rbuf[j & 1][i];
-                    v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                    v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
-                    v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                    v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+                    v0 += st_unpack((uint16_t)(rv.x & 0xffff));
+                    v1 += st_unpack((uint16_t)(rv.x >> 16));
+                    v2 += st_unpack((uint16_t)(rv.y & 0xffff));
+                    v3 += st_unpack((uint16_t)(rv.y >> 16));
                 }
                 const bool ok = (mt + m < p.M) && (n < p.N);
                 const unsigned voff = ok ? (unsigned)(m * p.ld_out + n) * (unsigned)esz : kOOB;
@@ -317,7 +310,7 @@ conv_v3_kernel(const ConvArgs p) {
                     const u32x4 o = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
                     __builtin_amdgcn_raw_buffer_store_b128(o, o_rsrc, voff, 0, 0);
                 } else {
-                    const u32x2 o = {pack2_bf16(v0, v1), pack2_bf16(v2, v3)};
+                    const u32x2 o = {st_pack2(v0, v1), st_pack2(v2, v3)};
                     __builtin_amdgcn_raw_buffer_store_b64(o, o_rsrc, voff, 0, 0);
                 }
             }
@@ -340,7 +333,7 @@ conv_v3_kernel(const ConvArgs p) {
     wait_vm_lgkm0<3 * PPW>();
     __builtin_amdgcn_s_barrier();
 
-    bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+    frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) xa[i] = read_x(0, i);
 #pragma unroll
@@ -365,7 +358,7 @@ conv_v3_kernel(const ConvArgs p) {
         if constexpr ((PROF & 64) == 0) {                                                          \
             _Pragma("unroll") for (int j = 0; j < FN; ++j)                                         \
                 _Pragma("unroll") for (int i = 0; i < FM; ++i)                                     \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j], XC[i], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = MDHIP_MFMA(WC[j], XC[i], acc[i][j]); \
         }                                                                                          \
     }
 
@@ -453,4 +446,5 @@ hipError_t conv3_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+}  // namespace MDHIP_ST
 }  // namespace mdhip

@@ -30,28 +30,21 @@
 #include "mdhip_internal.h"
 
 namespace mdhip {
+namespace MDHIP_ST {
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) char lds_char;
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr unsigned kOOB = 0x80000000u;
-constexpr int kNumRecords = 0x7fffffff;
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;
+[[maybe_unused]] constexpr int kNumRecords = 0x7fffffff;
 
 __device__ __forceinline__ float silu_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
-    const f32x2_t v = {a, b};
-    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
-    return *(const uint32_t*)&r;
 }
 
 constexpr int v4_patch_pieces(int r, int wt) { return ((r + 2) * (wt + 2) + 7) / 8; }
@@ -219,13 +212,13 @@ conv_v4_kernel(const ConvArgs p) {
         const int idx = fidx[i] + shift;
         a_addr[i] = (unsigned)(P_OFF + buf * P_BYTES + idx * 128 + ((c0 ^ (idx & 7)) << 4));
     };
-    auto read_x = [&](int i, int kk) __attribute__((always_inline)) -> bf16x8 {
-        return *(const __attribute__((address_space(3))) bf16x8*)(smem + (a_addr[i] ^ (unsigned)(kk * 64)));
+    auto read_x = [&](int i, int kk) __attribute__((always_inline)) -> frag8_t {
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + (a_addr[i] ^ (unsigned)(kk * 64)));
     };
     // B: as conv_igemm.cpp: row (lane & 15) of a 16-row fragment, chunk (lane>>4) ^ (row & 7), k 32..63 is ^ 64
     const int b_frag_base = (wn * TN) * 128 + (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) * 16);
-    auto read_w = [&](int stage, int kk, int j) __attribute__((always_inline)) -> bf16x8 {
-        return *(const __attribute__((address_space(3))) bf16x8*)(smem + stage * B_BYTES + ((b_frag_base + j * 2048) ^ (kk * 64)));
+    auto read_w = [&](int stage, int kk, int j) __attribute__((always_inline)) -> frag8_t {
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + stage * B_BYTES + ((b_frag_base + j * 2048) ^ (kk * 64)));
     };
 
     f32x4 acc[FM][FN];
@@ -297,10 +290,10 @@ conv_v4_kernel(const ConvArgs p) {
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (HAS_RES) {
                     const uint2 rv = rrow[i & 1][j];
-                    v[j][0] += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                    v[j][1] += bf16_to_f32((uint16_t)(rv.x >> 16));
-                    v[j][2] += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                    v[j][3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+                    v[j][0] += st_unpack((uint16_t)(rv.x & 0xffff));
+                    v[j][1] += st_unpack((uint16_t)(rv.x >> 16));
+                    v[j][2] += st_unpack((uint16_t)(rv.y & 0xffff));
+                    v[j][3] += st_unpack((uint16_t)(rv.y >> 16));
                 }
             }
             if constexpr ((PROF & 2) != 0) {
@@ -317,8 +310,8 @@ conv_v4_kernel(const ConvArgs p) {
             } else {
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
-                    const unsigned a0 = pack2_bf16(v[j][0], v[j][1]), a1 = pack2_bf16(v[j][2], v[j][3]);
-                    const unsigned b0 = pack2_bf16(v[j + 1][0], v[j + 1][1]), b1 = pack2_bf16(v[j + 1][2], v[j + 1][3]);
+                    const unsigned a0 = st_pack2(v[j][0], v[j][1]), a1 = st_pack2(v[j][2], v[j][3]);
+                    const unsigned b0 = st_pack2(v[j + 1][0], v[j + 1][1]), b1 = st_pack2(v[j + 1][2], v[j + 1][3]);
                     const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     const auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
@@ -332,7 +325,7 @@ conv_v4_kernel(const ConvArgs p) {
                     const int j = FN - 1;
                     const int n = nbase + j * 16;
                     const unsigned voff = (n < p.N) ? (unsigned)(mrel[i] * p.ld_out + n) * 2u : kOOB;
-                    const u32x2 o = {pack2_bf16(v[j][0], v[j][1]), pack2_bf16(v[j][2], v[j][3])};
+                    const u32x2 o = {st_pack2(v[j][0], v[j][1]), st_pack2(v[j][2], v[j][3])};
                     __builtin_amdgcn_raw_buffer_store_b64(o, o_rsrc, voff, 0, 0);
                 }
             }
@@ -354,7 +347,7 @@ conv_v4_kernel(const ConvArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+    frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
     set_a_addr(0, 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) xa[i] = read_x(i, 0);
@@ -399,7 +392,7 @@ conv_v4_kernel(const ConvArgs p) {
             MDHIP_FENCE();
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], xa[i], acc[i][g], 0, 0, 0);
+                acc[i][g] = MDHIP_MFMA(wa[g], xa[i], acc[i][g]);
             MDHIP_FENCE();
         }
 
@@ -428,7 +421,7 @@ conv_v4_kernel(const ConvArgs p) {
             if (!skip_y) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], xb[i], acc[i][g], 0, 0, 0);
+                    acc[i][g] = MDHIP_MFMA(wb[g], xb[i], acc[i][g]);
             }
             MDHIP_FENCE();
             if (g < B_PER) dma_b_piece(cur, g);
@@ -529,4 +522,5 @@ hipError_t conv4_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+}  // namespace MDHIP_ST
 }  // namespace mdhip

@@ -34,26 +34,19 @@
 #include "mdhip_internal.h"
 
 namespace mdhip {
+namespace MDHIP_ST {
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) char lds_char;
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr unsigned kOOB = 0x80000000u;
-constexpr int kNumRecords = 0x7fffffff;
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;
+[[maybe_unused]] constexpr int kNumRecords = 0x7fffffff;
 
 __device__ __forceinline__ float silu_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
-    const f32x2_t v = {a, b};
-    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
-    return *(const uint32_t*)&r;
 }
 
 constexpr int v5_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
@@ -214,11 +207,11 @@ conv_v5_kernel(const ConvArgs p) {
         const unsigned a = a_sh[s] + (unsigned)(buf * A_BUF + i * 2048);
         a_eff[i] = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
     };
-    auto read_x = [&](int i, int kk) -> bf16x8 {
-        return *(const __attribute__((address_space(3))) bf16x8*)(smem + (a_eff[i] ^ (unsigned)(kk * 64)));
+    auto read_x = [&](int i, int kk) -> frag8_t {
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + (a_eff[i] ^ (unsigned)(kk * 64)));
     };
-    auto read_w = [&](int stage, int kk, int j) -> bf16x8 {
-        return *(const __attribute__((address_space(3))) bf16x8*)(smem + stage * B_BYTES + j * 2048 +
+    auto read_w = [&](int stage, int kk, int j) -> frag8_t {
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + stage * B_BYTES + j * 2048 +
                                                                  (b_frag_base ^ (kk * 64)));
     };
 
@@ -280,10 +273,10 @@ conv_v5_kernel(const ConvArgs p) {
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (HAS_RES) {
                     const uint2 rv = rrow[i & 1][j];
-                    v[j][0] += bf16_to_f32((uint16_t)(rv.x & 0xffff));
-                    v[j][1] += bf16_to_f32((uint16_t)(rv.x >> 16));
-                    v[j][2] += bf16_to_f32((uint16_t)(rv.y & 0xffff));
-                    v[j][3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+                    v[j][0] += st_unpack((uint16_t)(rv.x & 0xffff));
+                    v[j][1] += st_unpack((uint16_t)(rv.x >> 16));
+                    v[j][2] += st_unpack((uint16_t)(rv.y & 0xffff));
+                    v[j][3] += st_unpack((uint16_t)(rv.y >> 16));
                 }
             }
             if constexpr ((PROF & 2) != 0) {
@@ -300,8 +293,8 @@ conv_v5_kernel(const ConvArgs p) {
                 uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
-                    unsigned a0 = pack2_bf16(v[j][0], v[j][1]), a1 = pack2_bf16(v[j][2], v[j][3]);
-                    unsigned b0 = pack2_bf16(v[j + 1][0], v[j + 1][1]), b1 = pack2_bf16(v[j + 1][2], v[j + 1][3]);
+                    unsigned a0 = st_pack2(v[j][0], v[j][1]), a1 = st_pack2(v[j][2], v[j][3]);
+                    unsigned b0 = st_pack2(v[j + 1][0], v[j + 1][1]), b1 = st_pack2(v[j + 1][2], v[j + 1][3]);
                     auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                     auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
@@ -313,8 +306,8 @@ conv_v5_kernel(const ConvArgs p) {
                     const int j = FN - 1;
                     const int n = nbase + j * 16;
                     uint2 o;
-                    o.x = pack2_bf16(v[j][0], v[j][1]);
-                    o.y = pack2_bf16(v[j][2], v[j][3]);
+                    o.x = st_pack2(v[j][0], v[j][1]);
+                    o.y = st_pack2(v[j][2], v[j][3]);
                     if (m < p.M && n < p.N) *(uint2*)(orow + n) = o;
                 }
             }
@@ -350,7 +343,7 @@ conv_v5_kernel(const ConvArgs p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+    frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
     tile_masks(first_tile);
 #pragma unroll
     for (int i = 0; i < FM; ++i) set_a_eff_one(0, 0, 0, i);
@@ -398,7 +391,7 @@ conv_v5_kernel(const ConvArgs p) {
                 MDHIP_FENCE();
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], xa[i], acc[i][g], 0, 0, 0);
+                    acc[i][g] = MDHIP_MFMA(wa[g], xa[i], acc[i][g]);
                 MDHIP_FENCE();
             }
 
@@ -424,7 +417,7 @@ conv_v5_kernel(const ConvArgs p) {
                 if (!skip_y) {
 #pragma unroll
                     for (int i = 0; i < FM; ++i)
-                        acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], xb[i], acc[i][g], 0, 0, 0);
+                        acc[i][g] = MDHIP_MFMA(wb[g], xb[i], acc[i][g]);
                 }
                 MDHIP_FENCE();
 #pragma unroll
@@ -524,4 +517,5 @@ hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+}  // namespace MDHIP_ST
 }  // namespace mdhip

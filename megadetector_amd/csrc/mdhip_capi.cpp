@@ -179,9 +179,10 @@ struct Planner {
         return s;
     }
 
-    // pack one or more OIHW fp32 convs (stacked along N) to bf16 [n_rows][k_pad], k = (r,s,c)
+    // pack one or more OIHW fp32 convs (stacked along N) to bf16 / fp16 [n_rows][k_pad], k = (r,s,c)
     int pack(const std::vector<const mdhip_conv*>& cs, bool s2d_stem) {
         PackedConv pc;
+        const int f16 = ctx->dtype == MDHIP_DTYPE_FP16;
         const mdhip_conv* c0 = cs[0];
         int c_out = 0;
         for (auto* c : cs) c_out += c->c_out;
@@ -212,7 +213,7 @@ struct Planner {
                             for (int s = 0; s < 6; ++s) {
                                 const float v = c->weight[(((size_t)o * 3 + ci) * 6 + r) * 6 + s];
                                 const int rp = r >> 1, dy = r & 1, sp = s >> 1, dx = s & 1;
-                                dst[(rp * 3 + sp) * 16 + (dy * 2 + dx) * 3 + ci] = f32_to_bf16(v);
+                                dst[(rp * 3 + sp) * 16 + (dy * 2 + dx) * 3 + ci] = f32_to_st(v, f16);
                             }
                 } else {
                     for (int ci = 0; ci < c->c_in; ++ci)
@@ -220,7 +221,7 @@ struct Planner {
                             for (int s = 0; s < c->kw; ++s) {
                                 const float v =
                                     c->weight[(((size_t)o * c->c_in + ci) * c->kh + r) * c->kw + s];
-                                dst[(r * c->kw + s) * pc.cin_pad + ci] = f32_to_bf16(v);
+                                dst[(r * c->kw + s) * pc.cin_pad + ci] = f32_to_st(v, f16);
                             }
                 }
             }
@@ -521,6 +522,27 @@ int check_shape(mdhip_ctx* ctx, int n, int h, int w) {
     return MDHIP_OK;
 }
 
+// the conv API of the context's storage type (the kernels are compiled once per type, mdhip_internal.h)
+struct ConvApi {
+    int (*num_cfgs)();
+    const ConvCfg& (*cfg)(int);
+    hipError_t (*launch)(int, const ConvArgs&, hipStream_t);
+    hipError_t (*init)();
+    bool (*supports)(int, const ConvArgs&);
+    bool (*is_bitwise_family)(int);
+    int (*num_v1_cfgs)();
+};
+const ConvApi g_conv_bf16 = {st_bf16::conv_num_cfgs, st_bf16::conv_cfg, st_bf16::conv_launch, st_bf16::conv_init,
+                             st_bf16::conv_supports, st_bf16::conv_cfg_is_bitwise_family, st_bf16::conv_num_v1_cfgs};
+const ConvApi g_conv_f16 = {st_f16::conv_num_cfgs, st_f16::conv_cfg, st_f16::conv_launch, st_f16::conv_init,
+                            st_f16::conv_supports, st_f16::conv_cfg_is_bitwise_family, st_f16::conv_num_v1_cfgs};
+inline const ConvApi& conv_api(const mdhip_ctx* ctx) { return ctx->dtype == MDHIP_DTYPE_FP16 ? g_conv_f16 : g_conv_bf16; }
+// tile configurations (count, names, families) are the same for both storage types
+inline int conv_num_cfgs() { return g_conv_bf16.num_cfgs(); }
+inline const ConvCfg& conv_cfg(int i) { return g_conv_bf16.cfg(i); }
+inline bool conv_cfg_is_bitwise_family(int c) { return g_conv_bf16.is_bitwise_family(c); }
+inline int conv_num_v1_cfgs() { return g_conv_bf16.num_v1_cfgs(); }
+
 // heuristic tile choice; measured overrides arrive through mdhip_set_op_cfg
 int choose_cfg(int M, int n_rows) {
     // prior from measurements on MI355X (profiles/autotune_r1.txt); tools/autotune.py refines it
@@ -611,7 +633,7 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
                         continue;
                     const double t_img = (double)t.m / (t.batch > 0 ? t.batch : 32);
                     const double r = t_img > m_img ? t_img / m_img : m_img / t_img;
-                    if (r < best && r <= 4.0 && conv_supports(t.cfg, a)) {
+                    if (r < best && r <= 4.0 && conv_api(ctx).supports(t.cfg, a)) {
                         best = r;
                         cfg = t.cfg;
                         from_table = true;
@@ -619,11 +641,11 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
                 }
             }
             if (cfg < 0) cfg = choose_cfg(a.M, a.n_rows);
-            hipError_t le = conv_launch(cfg, a, s);
+            hipError_t le = conv_api(ctx).launch(cfg, a, s);
             if (le == hipErrorInvalidValue && from_table) {      // table entry from another build: not applicable
                 (void)hipGetLastError();
                 cfg = choose_cfg(a.M, a.n_rows);
-                le = conv_launch(cfg, a, s);
+                le = conv_api(ctx).launch(cfg, a, s);
             }
             op.last_cfg = cfg;
             HIP_TRY(ctx, le);
@@ -633,7 +655,7 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             const int H = h / op.in.div, W = w / op.in.div;
             op.flops = 0;
             op.bytes = (double)n * H * W * op.in.c * 2.0 * 4.0;
-            HIP_TRY(ctx, launch_sppf_pool((uint16_t*)(ctx->arena + op.out.off), op.out.ld, op.in.c, n, H, W, op.pool_k, s));
+            HIP_TRY(ctx, launch_sppf_pool((uint16_t*)(ctx->arena + op.out.off), op.out.ld, op.in.c, n, H, W, op.pool_k, ctx->dtype == MDHIP_DTYPE_FP16, s));
             break;
         }
         case OP_UPSAMPLE: {
@@ -686,7 +708,8 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     *out = nullptr;
     if (!model || !model->layers || !model->convs || model->n_layers < 1)
         return fail(nullptr, MDHIP_EINVAL, "empty model description");
-    if (dtype != MDHIP_DTYPE_BF16) return fail(nullptr, MDHIP_EUNSUPPORTED, "dtype %d not implemented (bf16 only)", dtype);
+    if (dtype != MDHIP_DTYPE_BF16 && dtype != MDHIP_DTYPE_FP16)
+        return fail(nullptr, MDHIP_EUNSUPPORTED, "dtype %d not implemented (bf16 and fp16 storage only)", dtype);
     if (max_batch < 1 || max_h < 64 || max_w < 64) return fail(nullptr, MDHIP_EINVAL, "bad capacity %d x %dx%d", max_batch, max_h, max_w);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -727,7 +750,7 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     ctx->layers.assign(model->layers, model->layers + model->n_layers);
 
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = conv_init();
+    if (e == hipSuccess) e = conv_api(ctx).init();
     if (e != hipSuccess) {
         delete ctx;
         return fail(nullptr, MDHIP_EHIP, "device init failed: %s", hipGetErrorString(e));
@@ -885,7 +908,7 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
     HIP_TRY(ctx, hipMemcpyAsync(ctx->arena + ctx->geom_off, gh, n * sizeof(LetterboxDev), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipEventRecord(ctx->geom_ev[slot], s));
     HIP_TRY(ctx, launch_letterbox_s2d((const LetterboxDev*)(ctx->arena + ctx->geom_off), n, out_h, out_w,
-                                      (uint16_t*)(ctx->arena + ctx->input.off), s));
+                                      (uint16_t*)(ctx->arena + ctx->input.off), ctx->dtype == MDHIP_DTYPE_FP16, s));
     ctx->last_n = n;
     ctx->last_h = out_h;
     ctx->last_w = out_w;
@@ -1068,7 +1091,7 @@ int mdhip_read_input(mdhip_ctx* ctx, int n, int h, int w, float* out, void* hip_
     float* tmp = nullptr;
     const size_t bytes = (size_t)n * 3 * h * w * 4;
     HIP_TRY(ctx, hipMalloc((void**)&tmp, bytes));
-    hipError_t e = launch_s2d_to_nchw_f32((const uint16_t*)(ctx->arena + ctx->input.off), tmp, n, h, w, s);
+    hipError_t e = launch_s2d_to_nchw_f32((const uint16_t*)(ctx->arena + ctx->input.off), tmp, n, h, w, ctx->dtype == MDHIP_DTYPE_FP16, s);
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(tmp);
@@ -1092,7 +1115,7 @@ int mdhip_read_layer(mdhip_ctx* ctx, int layer, int n, float* out, int* c, int* 
     float* tmp = nullptr;
     const size_t bytes = (size_t)n * t.c * H * W * 4;
     HIP_TRY(ctx, hipMalloc((void**)&tmp, bytes));
-    hipError_t e = launch_nhwc_to_nchw_f32((const uint16_t*)(ctx->arena + t.off), t.ld, tmp, n, t.c, H, W, s);
+    hipError_t e = launch_nhwc_to_nchw_f32((const uint16_t*)(ctx->arena + t.off), t.ld, tmp, n, t.c, H, W, ctx->dtype == MDHIP_DTYPE_FP16, s);
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(tmp);
@@ -1132,7 +1155,7 @@ int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg) {
     ConvArgs a;
     const int h = ctx->last_h ? ctx->last_h : ctx->max_stride, w = ctx->last_w ? ctx->last_w : ctx->max_stride;
     fill_conv_args(ctx, ctx->ops[op], ctx->last_n ? ctx->last_n : 1, h, w, a);
-    return conv_supports(cfg, a) ? 1 : 0;
+    return conv_api(ctx).supports(cfg, a) ? 1 : 0;
 }
 
 const char* mdhip_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs()) ? conv_cfg(cfg).name : ""; }

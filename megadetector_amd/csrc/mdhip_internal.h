@@ -8,7 +8,8 @@
 namespace mdhip {
 
 // ---------------------------------------------------------------------------------------
-// bf16 helpers (storage type of every activation and packed weight)
+// storage-type helpers.  Activations and packed weights are 16-bit: bf16 (the configuration BASELINE.json
+// names) or fp16 (same MFMA rate, 3 more mantissa bits; MDHIP_DTYPE_FP16).  Accumulation is fp32 either way.
 // ---------------------------------------------------------------------------------------
 __host__ __device__ inline uint16_t f32_to_bf16(float f) {
     union { float f; uint32_t u; } v;
@@ -23,6 +24,62 @@ __host__ __device__ inline float bf16_to_f32(uint16_t h) {
     v.u = ((uint32_t)h) << 16;
     return v.f;
 }
+__host__ __device__ inline uint16_t f32_to_f16(float f) {
+    union { _Float16 h; uint16_t u; } v;
+    v.h = (_Float16)f;                                                          // RNE, overflow -> inf
+    return v.u;
+}
+__host__ __device__ inline float f16_to_f32(uint16_t h) {
+    union { _Float16 h; uint16_t u; } v;
+    v.u = h;
+    return (float)v.h;
+}
+__host__ __device__ inline uint16_t f32_to_st(float f, int f16) { return f16 ? f32_to_f16(f) : f32_to_bf16(f); }
+__host__ __device__ inline float st_to_f32(uint16_t h, int f16) { return f16 ? f16_to_f32(h) : bf16_to_f32(h); }
+
+// The convolution translation units are compiled twice: as is (bf16, namespace mdhip::st_bf16) and with
+// -DMDHIP_ST_F16 (fp16, namespace mdhip::st_f16).  Inside them MDHIP_ST is that namespace, frag8_t the MFMA
+// operand type, MDHIP_MFMA the 16x16x32 instruction, st_pack2 / st_unpack the epilogue conversions.
+#if defined(MDHIP_ST_F16)
+#define MDHIP_ST st_f16
+#define MDHIP_ST_LABEL "fp16"
+#else
+#define MDHIP_ST st_bf16
+#define MDHIP_ST_LABEL "bf16"
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#if defined(MDHIP_ST_F16)
+typedef _Float16 frag8_t __attribute__((ext_vector_type(8)));
+#define MDHIP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ uint32_t st_pack2(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    const h2 r = __builtin_convertvector(v, h2);
+    return *(const uint32_t*)&r;
+}
+__device__ __forceinline__ float st_unpack(uint16_t h) { return f16_to_f32(h); }
+#else
+typedef short frag8_t __attribute__((ext_vector_type(8)));
+#define MDHIP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ uint32_t st_pack2(float a, float b) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    const b2 r = __builtin_convertvector(v, b2);
+    return *(const uint32_t*)&r;
+}
+__device__ __forceinline__ float st_unpack(uint16_t h) { return bf16_to_f32(h); }
+#endif
+// a fragment that is not read from LDS (ablation variants of the kernels only)
+__device__ __forceinline__ frag8_t frag_dummy(int v) {
+    frag8_t z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (__typeof__(z[0]))(v + k);
+    asm volatile("" : "+v"(z));
+    return z;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------
 // implicit-GEMM convolution (conv_igemm.cpp)
@@ -57,38 +114,51 @@ struct ConvCfg {
     const char* name;
 };
 
-int conv_num_cfgs();
-const ConvCfg& conv_cfg(int i);
-// returns hipSuccess or the launch error
-hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s);
-hipError_t conv_init();   // one-off: raise dynamic-LDS limits
-bool conv_supports(int cfg, const ConvArgs& a);
-bool conv_cfg_is_bitwise_family(int cfg);   // false: same result up to fp32 summation order only   // can configuration `cfg` run this op?
-int conv_num_v1_cfgs();   // ids below this run conv_igemm.cpp's kernel (every shape); the rest conv_v2.cpp's
-// second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
-int conv2_num_cfgs();
-const ConvCfg& conv2_cfg(int i);
-bool conv2_supports(const ConvArgs& a);
-hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s);
-hipError_t conv2_init();
-// third-generation main loop (conv_v3.cpp): 32-deep slabs, 4-stage ring, counted waits
-int conv3_num_cfgs();
-const ConvCfg& conv3_cfg(int i);
-bool conv3_supports(const ConvArgs& a);
-hipError_t conv3_launch(int cfg, const ConvArgs& a, hipStream_t s);
-hipError_t conv3_init();
-// row-patch direct convolution for 3x3 / stride 1 (conv_v4.cpp)
-int conv4_num_cfgs();
-const ConvCfg& conv4_cfg(int i);
-bool conv4_supports(int cfg, const ConvArgs& a);
-hipError_t conv4_launch(int cfg, const ConvArgs& a, hipStream_t s);
-hipError_t conv4_init();
-// 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp)
-int conv5_num_cfgs();
-const ConvCfg& conv5_cfg(int i);
-bool conv5_supports(int cfg, const ConvArgs& a);
-hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s);
-hipError_t conv5_init();
+// The conv API exists once per storage type (see MDHIP_ST above):
+//   conv_*  : dispatch over all kernels (conv_igemm.cpp); ids [0, conv_num_v1_cfgs()) run conv_igemm.cpp's
+//             kernel (every shape), then conv_v2.cpp's, conv_v3.cpp's, conv_v4.cpp's, conv_v5.cpp's
+//   conv2_* : second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
+//   conv3_* : 32-deep slabs, 4-stage ring, counted waits (conv_v3.cpp)
+//   conv4_* : row-patch direct convolution for 3x3 / stride 1 (conv_v4.cpp)
+//   conv5_* : 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp)
+// conv_launch returns hipSuccess or the launch error; conv_init raises the dynamic-LDS limits (one-off);
+// conv_cfg_is_bitwise_family is false for kernels whose result equals the others' up to fp32 summation
+// order only.
+#define MDHIP_CONV_API \
+    int conv_num_cfgs(); \
+    const ConvCfg& conv_cfg(int i); \
+    hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv_init(); \
+    bool conv_supports(int cfg, const ConvArgs& a); \
+    bool conv_cfg_is_bitwise_family(int cfg); \
+    int conv_num_v1_cfgs(); \
+    int conv2_num_cfgs(); \
+    const ConvCfg& conv2_cfg(int i); \
+    bool conv2_supports(const ConvArgs& a); \
+    hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv2_init(); \
+    int conv3_num_cfgs(); \
+    const ConvCfg& conv3_cfg(int i); \
+    bool conv3_supports(const ConvArgs& a); \
+    hipError_t conv3_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv3_init(); \
+    int conv4_num_cfgs(); \
+    const ConvCfg& conv4_cfg(int i); \
+    bool conv4_supports(int cfg, const ConvArgs& a); \
+    hipError_t conv4_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv4_init(); \
+    int conv5_num_cfgs(); \
+    const ConvCfg& conv5_cfg(int i); \
+    bool conv5_supports(int cfg, const ConvArgs& a); \
+    hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv5_init();
+namespace st_bf16 {
+MDHIP_CONV_API
+}
+namespace st_f16 {
+MDHIP_CONV_API
+}
+#undef MDHIP_CONV_API
 
 // ---------------------------------------------------------------------------------------
 // memory-bound helpers (misc_kernels.cpp)
@@ -99,9 +169,9 @@ struct LetterboxDev {     // device copy of mdhip_letterbox + source pointer
 };
 // u8 HWC -> space-to-depth bf16 [n][out_h/2][out_w/2][16] (12 real channels: (dy,dx,c)), /255
 hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, int n, int out_h, int out_w,
-                                uint16_t* out, hipStream_t s);
+                                uint16_t* out, int f16, hipStream_t s);
 // SPPF: three chained 5x5/s1/p2 max pools of slice 0 written to slices 1..3 of the same buffer
-hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, int k, hipStream_t s);
+hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, int k, int f16, hipStream_t s);
 // nearest x2 upsample of a view into a view
 hipError_t launch_upsample2x(const uint16_t* in, int ld_in, uint16_t* out, int ld_out, int c,
                              int n, int h, int w, hipStream_t s);
@@ -114,8 +184,8 @@ hipError_t launch_detect_decode(const float* logits, int ld, float* pred, int n,
                                 const float* anchors_px /*device, [na][2]*/, hipStream_t s);
 // debug readback: NHWC bf16 view -> NCHW fp32
 hipError_t launch_nhwc_to_nchw_f32(const uint16_t* in, int ld, float* out, int n, int c, int h,
-                                   int w, hipStream_t s);
-hipError_t launch_s2d_to_nchw_f32(const uint16_t* in, float* out, int n, int h, int w, hipStream_t s);
+                                   int w, int f16, hipStream_t s);
+hipError_t launch_s2d_to_nchw_f32(const uint16_t* in, float* out, int n, int h, int w, int f16, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // NMS (nms_kernels.cpp)

@@ -37,7 +37,7 @@ __device__ __forceinline__ void linear_coef(int d, int dst_len, int src_len, int
 
 __global__ void __launch_bounds__(256)
 letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w,
-                     uint16_t* __restrict__ out) {
+                     uint16_t* __restrict__ out, int f16) {
     const int img = blockIdx.z;
     const int X = blockIdx.x * blockDim.x + threadIdx.x;     // s2d column
     const int Y = blockIdx.y;                                // s2d row
@@ -80,7 +80,7 @@ letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                px[(dy * 2 + dx) * 3 + c] = f32_to_bf16((float)v[c] / 255.0f);
+                px[(dy * 2 + dx) * 3 + c] = f32_to_st((float)v[c] / 255.0f, f16);
         }
     }
     uint4* dst = (uint4*)(out + (((size_t)img * H2 + Y) * W2 + X) * 16);
@@ -94,25 +94,25 @@ letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w
 }
 
 hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, int n, int out_h, int out_w,
-                                uint16_t* out, hipStream_t s) {
+                                uint16_t* out, int f16, hipStream_t s) {
     const int W2 = out_w / 2, H2 = out_h / 2;
     dim3 grid((W2 + 255) / 256, H2, n);
-    hipLaunchKernelGGL(letterbox_s2d_kernel, grid, dim3(256), 0, s, geom_dev, out_h, out_w, out);
+    hipLaunchKernelGGL(letterbox_s2d_kernel, grid, dim3(256), 0, s, geom_dev, out_h, out_w, out, f16);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
-// 16-byte (8 x bf16) vector helpers
+// 16-byte (8 x bf16 / fp16) vector helpers
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t max2_bf16(uint32_t a, uint32_t b) {
-    const float a0 = bf16_to_f32((uint16_t)(a & 0xffff)), a1 = bf16_to_f32((uint16_t)(a >> 16));
-    const float b0 = bf16_to_f32((uint16_t)(b & 0xffff)), b1 = bf16_to_f32((uint16_t)(b >> 16));
+__device__ __forceinline__ uint32_t max2_st(uint32_t a, uint32_t b, int f16) {
+    const float a0 = st_to_f32((uint16_t)(a & 0xffff), f16), a1 = st_to_f32((uint16_t)(a >> 16), f16);
+    const float b0 = st_to_f32((uint16_t)(b & 0xffff), f16), b1 = st_to_f32((uint16_t)(b >> 16), f16);
     const uint32_t lo = (b0 > a0) ? (b & 0xffff) : (a & 0xffff);
     const uint32_t hi = (b1 > a1) ? (b >> 16) : (a >> 16);
     return lo | (hi << 16);
 }
-__device__ __forceinline__ uint4 max8_bf16(uint4 a, uint4 b) {
-    return make_uint4(max2_bf16(a.x, b.x), max2_bf16(a.y, b.y), max2_bf16(a.z, b.z), max2_bf16(a.w, b.w));
+__device__ __forceinline__ uint4 max8_st(uint4 a, uint4 b, int f16) {
+    return make_uint4(max2_st(a.x, b.x, f16), max2_st(a.y, b.y, f16), max2_st(a.z, b.z, f16), max2_st(a.w, b.w, f16));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -121,7 +121,7 @@ __device__ __forceinline__ uint4 max8_bf16(uint4 a, uint4 b) {
 // buf, y1..y3 go to slices 1..3 (yolov5 models/common.py:SPPF.forward).
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w, int r1) {
+sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w, int r1, int f16) {
     const long long total = (long long)n * h * w * c8;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -132,7 +132,7 @@ sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w
     const int b = (int)(pix / ((long long)w * h));
     const int c = c8 * 8;
     const uint16_t* base = buf + (size_t)b * h * w * ld + ch * 8;
-    const uint32_t ninf2 = 0xff80ff80u;   // two bf16 -inf
+    const uint32_t ninf2 = f16 ? 0xfc00fc00u : 0xff80ff80u;   // two -inf
     uint4 m1 = make_uint4(ninf2, ninf2, ninf2, ninf2), m2 = m1, m3 = m1;
     const int r3 = 3 * r1, r2 = 2 * r1;
     for (int dy = -r3; dy <= r3; ++dy) {
@@ -144,10 +144,10 @@ sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w
             if ((unsigned)xx >= (unsigned)w) continue;
             const int adx = dx < 0 ? -dx : dx;
             const uint4 v = *(const uint4*)(base + ((size_t)yy * w + xx) * ld);
-            m3 = max8_bf16(m3, v);
+            m3 = max8_st(m3, v, f16);
             const int ad = ady > adx ? ady : adx;
-            if (ad <= r2) m2 = max8_bf16(m2, v);
-            if (ad <= r1) m1 = max8_bf16(m1, v);
+            if (ad <= r2) m2 = max8_st(m2, v, f16);
+            if (ad <= r1) m1 = max8_st(m1, v, f16);
         }
     }
     uint16_t* o = buf + ((size_t)(b * h + y) * w + x) * ld + ch * 8;
@@ -156,10 +156,10 @@ sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w
     *(uint4*)(o + 3 * c) = m3;
 }
 
-hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, int k, hipStream_t s) {
+hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, int k, int f16, hipStream_t s) {
     const long long total = (long long)n * h * w * (c / 8);
     hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       buf, ld, c / 8, n, h, w, k / 2);
+                       buf, ld, c / 8, n, h, w, k / 2, f16);
     return hipGetLastError();
 }
 
@@ -253,7 +253,7 @@ hipError_t launch_detect_decode(const float* logits, int ld, float* pred, int n,
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 nhwc_to_nchw_f32_kernel(const uint16_t* __restrict__ in, int ld, float* __restrict__ out, int n,
-                        int c, int h, int w) {
+                        int c, int h, int w, int f16) {
     const long long total = (long long)n * c * h * w;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -261,19 +261,19 @@ nhwc_to_nchw_f32_kernel(const uint16_t* __restrict__ in, int ld, float* __restri
     const int y = (int)((t / w) % h);
     const int ch = (int)((t / ((long long)w * h)) % c);
     const int b = (int)(t / ((long long)w * h * c));
-    out[t] = bf16_to_f32(in[((size_t)(b * h + y) * w + x) * ld + ch]);
+    out[t] = st_to_f32(in[((size_t)(b * h + y) * w + x) * ld + ch], f16);
 }
 
 hipError_t launch_nhwc_to_nchw_f32(const uint16_t* in, int ld, float* out, int n, int c, int h,
-                                   int w, hipStream_t s) {
+                                   int w, int f16, hipStream_t s) {
     const long long total = (long long)n * c * h * w;
     hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       s, in, ld, out, n, c, h, w);
+                       s, in, ld, out, n, c, h, w, f16);
     return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256)
-s2d_to_nchw_f32_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int n, int h, int w) {
+s2d_to_nchw_f32_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int n, int h, int w, int f16) {
     const long long total = (long long)n * 3 * h * w;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -282,13 +282,13 @@ s2d_to_nchw_f32_kernel(const uint16_t* __restrict__ in, float* __restrict__ out,
     const int ch = (int)((t / ((long long)w * h)) % 3);
     const int b = (int)(t / ((long long)w * h * 3));
     const int H2 = h / 2, W2 = w / 2;
-    out[t] = bf16_to_f32(in[(((size_t)b * H2 + (y >> 1)) * W2 + (x >> 1)) * 16 + ((y & 1) * 2 + (x & 1)) * 3 + ch]);
+    out[t] = st_to_f32(in[(((size_t)b * H2 + (y >> 1)) * W2 + (x >> 1)) * 16 + ((y & 1) * 2 + (x & 1)) * 3 + ch], f16);
 }
 
-hipError_t launch_s2d_to_nchw_f32(const uint16_t* in, float* out, int n, int h, int w, hipStream_t s) {
+hipError_t launch_s2d_to_nchw_f32(const uint16_t* in, float* out, int n, int h, int w, int f16, hipStream_t s) {
     const long long total = (long long)n * 3 * h * w;
     hipLaunchKernelGGL(s2d_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       s, in, out, n, h, w);
+                       s, in, out, n, h, w, f16);
     return hipGetLastError();
 }
 

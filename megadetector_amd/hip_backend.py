@@ -60,7 +60,8 @@ class HipContext:
         self._keep += [anchors, strides, layers, conv_arr]
         m.anchors_px = anchors.ctypes.data_as(C.POINTER(C.c_float)) if anchors.size else None
         m.strides = strides.ctypes.data_as(C.POINTER(C.c_float)) if strides.size else None
-        dt = {'bf16': _lib.MDHIP_DTYPE_BF16, 'fp8': _lib.MDHIP_DTYPE_FP8}[dtype]
+        dt = {'bf16': _lib.MDHIP_DTYPE_BF16, 'fp8': _lib.MDHIP_DTYPE_FP8, 'fp16': _lib.MDHIP_DTYPE_FP16}[dtype]
+        self.dtype = dtype
         handle = C.c_void_p()
         rc = self.lib.mdhip_create(C.byref(m), self.device, dt, int(max_batch), int(max_h), int(max_w),
                                    C.byref(handle))

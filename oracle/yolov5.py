@@ -113,6 +113,10 @@ def _bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def _fp16_round(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
 class Forward:
     """
     Functional YOLOv5 forward on CPU.
@@ -124,17 +128,19 @@ class Forward:
                          logits kept fp32) so the HIP kernels can be checked tightly;
                          residual adds and SiLU are evaluated in fp32 before rounding,
                          exactly as the fused HIP epilogue does.
+    emulate_bf16='fp16': the same with fp16 storage (the HIP path's MDHIP_DTYPE_FP16 mode).
     """
 
     def __init__(self, yaml, weights, emulate_bf16=False, keep=None):
         self.yaml = yaml
         self.layers = parse_model(yaml)
-        self.emulate = emulate_bf16
+        self.emulate = bool(emulate_bf16)
+        self._round = _fp16_round if emulate_bf16 == 'fp16' else _bf16_round
         self.w = {}
         for k, v in weights.items():
             v = v.detach().to(torch.float32)
             if emulate_bf16 and k.endswith('.weight'):
-                v = _bf16_round(v)
+                v = self._round(v)
             self.w[k] = v
         self.keep = keep          # optional dict: layer index -> output tensor (NCHW fp32)
         det = self.layers[-1]
@@ -151,7 +157,7 @@ class Forward:
         if residual is not None:
             y = residual + y
         if self.emulate:
-            y = _bf16_round(y)
+            y = self._round(y)
         return y
 
     def _c3(self, x, L):
@@ -204,7 +210,7 @@ class Forward:
     def __call__(self, x):
         """x: (B,3,H,W) fp32 in [0,1].  Returns (B, n_anchors, 5+nc) fp32."""
         if self.emulate:
-            x = _bf16_round(x)
+            x = self._round(x)
         in_hw = x.shape[2:]
         outs = []
         for L in self.layers:

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""
+Accuracy of the two storage modes against the fp32 oracle (= what the reference computes), on the seeded
+test networks and on a checkpoint written by tests/fake_yolov5.py: max |d conf| over all anchors and
+over the confident ones, box error.  Prints a table (GPU box); numbers quoted in DESIGN.md section 3.
+"""
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+
+
+def main():
+    import fake_yolov5 as FY
+    import parity_util as PU
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    cases = []
+    for name, seed in (('YOLOV5N6_TEST', 1), ('YOLOV5S6_TEST', 3)):
+        cases.append(('synthetic ' + name, weights_io.synthetic_weights(getattr(yolo_yaml, name), seed=seed)))
+    model = FY.build_model(yolo_yaml.YOLOV5S6_TEST, seed=7)
+    FY.save_checkpoint(model, '/tmp/acc_fake.pt')
+    FY.uninstall()
+    cases.append(('checkpoint (fake_yolov5 S6)', weights_io.load_checkpoint('/tmp/acc_fake.pt')))
+    hh, ww = 384, 640
+    imgs = PU.structured_images(2, hh, ww, seed=71)
+    x, _ = PU.oracle_input(imgs, ww, 64)
+    print('{:30s} {:5s} {:>12s} {:>14s} {:>12s} {:>12s}'.format('weights', 'dtype', 'max|dconf|', 'max|dconf|>0.1', 'box rel max', 'box rel mean'))
+    for label, W in cases:
+        p32, _ = PU.oracle_forward(W, x, emulate_bf16=False)
+        p32 = p32.numpy()
+        for dtype in ('bf16', 'fp16'):
+            ctx = HipContext(W, device=0, dtype=dtype, max_batch=2, max_h=hh, max_w=ww)
+            ctx.preprocess(imgs, [(hh, ww, hh, ww, 0, 0)] * 2, hh, ww)
+            ctx.forward(2, hh, ww)
+            got = ctx.read_predictions(2, hh, ww)
+            ctx.close()
+            d = np.abs(got[..., 4:] - p32[..., 4:])
+            score = (p32[..., 4:5] * p32[..., 5:]).max(-1)
+            hi = score > 0.1
+            e = PU.rel_err(got[..., :4], p32[..., :4])
+            print('{:30s} {:5s} {:12.5f} {:14.5f} {:12.2e} {:12.2e}   ({} confident anchors)'.format(
+                label, dtype, d.max(), d[hi].max() if hi.any() else float('nan'), e[0], e[1], int(hi.sum())))
+
+
+if __name__ == '__main__':
+    main()

@@ -109,6 +109,73 @@ def test_every_layer_matches_bf16_oracle(n6):
     assert np.abs(pred[..., 4:] - pred_ref[..., 4:].numpy()).max() < 2e-2
 
 
+# fp16 storage (MDHIP_DTYPE_FP16): 11 significant bits instead of 8
+F16_LAYER_MAX_TOL = 4e-3
+F16_LAYER_MEAN_TOL = 1e-3
+F16_CONF_TOL_FP32_ORACLE = 0.01     # the reference's own bar between environments (md_tests.py:96-100)
+
+
+def test_fp16_storage_mode_layers_and_end_to_end():
+    """
+    dtype='fp16': the same kernels built for fp16 storage.  Preprocess bit-exact, every layer against the
+    fp16-emulating oracle (tolerances 8x tighter than bf16), both summation-order families, batch
+    invariance bitwise, and the decoded confidences against the *fp32* oracle (= what the reference
+    computes) within the reference's own cross-environment tolerance of 0.01.
+    """
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5S6_TEST, seed=3)
+    HH, WW = 384, 640
+    ctx = HipContext(W, device=0, dtype='fp16', max_batch=2, max_h=HH, max_w=WW)
+    try:
+        imgs = PU.structured_images(2, HH, WW, seed=61)
+        ctx.preprocess(imgs, _identity_geoms(imgs), HH, WW)
+        x, _ = PU.oracle_input(imgs, WW, 64)
+        assert tuple(x.shape[2:]) == (HH, WW)
+        np.testing.assert_array_equal(ctx.read_input(2, HH, WW), x.half().float().numpy())
+        keep = {}
+        pred16, _ = PU.oracle_forward(W, x, emulate_bf16='fp16', keep=keep)
+        pred32, _ = PU.oracle_forward(W, x, emulate_bf16=False)
+        convs = [o['op'] for o in ctx.op_infos() if o['kind'] == 0]
+        families = {}
+        for cfg in [-1] + [c for c in range(ctx.num_conv_cfgs()) if not ctx.cfg_is_bitwise(c)]:
+            switched = [op for op in convs if cfg >= 0 and ctx.op_supports_cfg(op, cfg)]
+            if cfg >= 0 and not switched:
+                continue
+            for op in convs:
+                ctx.set_op_cfg(op, cfg if op in switched else -1)
+            ctx.forward(2, HH, WW)
+            bad = []
+            for i in sorted(keep):
+                e = PU.rel_err(ctx.read_layer(i, 2), keep[i].numpy())
+                if e[0] > F16_LAYER_MAX_TOL or e[1] > F16_LAYER_MEAN_TOL:
+                    bad.append((i,) + e)
+            assert not bad, (cfg, bad)
+            got = ctx.read_predictions(2, HH, WW).copy()
+            families[cfg] = got
+            emax, emean = PU.rel_err(got[..., :4], pred16[..., :4].numpy())
+            assert emax < 4e-3 and emean < 1e-3, (cfg, emax, emean)
+            d32 = float(np.abs(got[..., 4:] - pred32[..., 4:].numpy()).max())
+            assert d32 < F16_CONF_TOL_FP32_ORACLE, (cfg, d32)
+            # batch composition invariance: bitwise
+            ctx.preprocess([imgs[1]], _identity_geoms([imgs[1]]), HH, WW)
+            ctx.forward(1, HH, WW)
+            np.testing.assert_array_equal(ctx.read_predictions(1, HH, WW)[0], got[1])
+            ctx.preprocess(imgs, _identity_geoms(imgs), HH, WW)
+        assert len(families) >= 2, 'no row-segment / row-patch kernel took part'
+        # all v1 tile configurations stay bitwise-identical in the fp16 build as well
+        for op in convs:
+            ctx.set_op_cfg(op, -1)
+        base = families[-1]
+        for cfg in (0, 5, 15):
+            for op in convs:
+                ctx.set_op_cfg(op, cfg)
+            ctx.forward(2, HH, WW)
+            np.testing.assert_array_equal(ctx.read_predictions(2, HH, WW), base)
+    finally:
+        ctx.close()
+
+
 def test_p5_family_member_with_other_class_count():
     """
     SURVEY.md 8(f) N4: the same kernels on a P5 network (3 Detect levels, max stride 32, as MDv1000-spruce =

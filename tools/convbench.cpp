@@ -19,6 +19,7 @@
 #include "../megadetector_amd/csrc/mdhip_internal.h"
 
 using namespace mdhip;
+using namespace mdhip::st_bf16;
 
 #define CK(x)                                                                         \
     do {                                                                              \
