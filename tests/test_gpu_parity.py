@@ -349,6 +349,32 @@ def test_batch_composition_invariance_with_measured_table():
         ctx.close()
 
 
+def test_cabi_error_returns_do_not_poison_the_context(n6):
+    """C ABI conventions (include/mdhip.h): bad arguments return an error code with a message, nothing
+    throws or exits, and the context keeps working afterwards."""
+    from megadetector_amd._lib import HipError
+    W, ctx = n6
+    imgs = PU.random_images(2, 256, 256, seed=77)
+    ctx.preprocess(imgs, _identity_geoms(imgs), 256, 256)
+    ctx.forward(2, 256, 256)
+    good = ctx.read_predictions(2, 256, 256).copy()
+    with pytest.raises(HipError, match='batch'):
+        ctx.forward(ctx.max_batch + 1, 256, 256)
+    with pytest.raises(HipError, match='multiple of the model stride'):
+        ctx.forward(1, 250, 256)
+    with pytest.raises(HipError, match='exceeds the planned'):
+        ctx.forward(1, 640, 640)
+    with pytest.raises(HipError, match='does not fit'):
+        ctx.preprocess(imgs, [(256, 256, 300, 256, 0, 0)] * 2, 256, 256)
+    with pytest.raises(HipError):
+        ctx.set_op_cfg(0, 10 ** 6)
+    with pytest.raises(HipError):
+        ctx.nms_on(np.zeros((1, 10, 8), np.float32), 0.1, 0.45, max_det=10 ** 6)
+    ctx.preprocess(imgs, _identity_geoms(imgs), 256, 256)
+    ctx.forward(2, 256, 256)
+    np.testing.assert_array_equal(ctx.read_predictions(2, 256, 256), good)
+
+
 # ---------------------------------------------------------------------------------------
 # NMS: bit-exact against the reference fixtures and the oracle
 # ---------------------------------------------------------------------------------------
