@@ -117,11 +117,14 @@ __device__ __forceinline__ uint4 max8_st(uint4 a, uint4 b, int f16) {
 
 // ---------------------------------------------------------------------------------------
 // SPPF pools: y1 = maxpool k(x), y2 = maxpool k(y1), y3 = maxpool k(y2)  (stride 1, pad k/2,
-// -inf padding) == max over the (k), (2k-1), (3k-2) windows of x.  x is channel slice 0 of
-// buf, y1..y3 go to slices 1..3 (yolov5 models/common.py:SPPF.forward).
+// -inf padding).  x is channel slice 0 of buf, y1..y3 go to slices 1..3 (yolov5
+// models/common.py:SPPF.forward).
 // ---------------------------------------------------------------------------------------
+// one k x k / stride 1 max pool of channel slice `src` into slice `src + 1` of the same buffer; the three
+// chained pools of SPPF are three launches (75 loads per output instead of the 169 of the fused
+// (k), (2k-1), (3k-2) windows: 0.45 -> 0.1 ms per step at batch 32)
 __global__ void __launch_bounds__(256)
-sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w, int r1, int f16) {
+sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w, int r1, int src, int f16) {
     const long long total = (long long)n * h * w * c8;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -131,35 +134,26 @@ sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w
     const int y = (int)((pix / w) % h);
     const int b = (int)(pix / ((long long)w * h));
     const int c = c8 * 8;
-    const uint16_t* base = buf + (size_t)b * h * w * ld + ch * 8;
+    const uint16_t* base = buf + (size_t)b * h * w * ld + src * c + ch * 8;
     const uint32_t ninf2 = f16 ? 0xfc00fc00u : 0xff80ff80u;   // two -inf
-    uint4 m1 = make_uint4(ninf2, ninf2, ninf2, ninf2), m2 = m1, m3 = m1;
-    const int r3 = 3 * r1, r2 = 2 * r1;
-    for (int dy = -r3; dy <= r3; ++dy) {
+    uint4 m = make_uint4(ninf2, ninf2, ninf2, ninf2);
+    for (int dy = -r1; dy <= r1; ++dy) {
         const int yy = y + dy;
         if ((unsigned)yy >= (unsigned)h) continue;
-        const int ady = dy < 0 ? -dy : dy;
-        for (int dx = -r3; dx <= r3; ++dx) {
+        for (int dx = -r1; dx <= r1; ++dx) {
             const int xx = x + dx;
             if ((unsigned)xx >= (unsigned)w) continue;
-            const int adx = dx < 0 ? -dx : dx;
-            const uint4 v = *(const uint4*)(base + ((size_t)yy * w + xx) * ld);
-            m3 = max8_st(m3, v, f16);
-            const int ad = ady > adx ? ady : adx;
-            if (ad <= r2) m2 = max8_st(m2, v, f16);
-            if (ad <= r1) m1 = max8_st(m1, v, f16);
+            m = max8_st(m, *(const uint4*)(base + ((size_t)yy * w + xx) * ld), f16);
         }
     }
-    uint16_t* o = buf + ((size_t)(b * h + y) * w + x) * ld + ch * 8;
-    *(uint4*)(o + c) = m1;
-    *(uint4*)(o + 2 * c) = m2;
-    *(uint4*)(o + 3 * c) = m3;
+    *(uint4*)(buf + ((size_t)(b * h + y) * w + x) * ld + (src + 1) * c + ch * 8) = m;
 }
 
 hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, int k, int f16, hipStream_t s) {
     const long long total = (long long)n * h * w * (c / 8);
-    hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       buf, ld, c / 8, n, h, w, k / 2, f16);
+    for (int src = 0; src < 3; ++src)
+        hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           buf, ld, c / 8, n, h, w, k / 2, src, f16);
     return hipGetLastError();
 }
 
