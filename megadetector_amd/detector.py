@@ -188,7 +188,21 @@ class HIPDetector:
             detection_threshold = 0.0
         if self._ctx is None:
             raise RuntimeError('this HIPDetector was created with preprocess_only')
+        results, shape_groups = self._prepare_batch(img_original, image_id, image_size, verbose)
+        for shape, items in shape_groups.items():
+            try:
+                for start in range(0, len(items), self.max_batch):
+                    self._process_batch_group(items[start:start + self.max_batch], results,
+                                              detection_threshold, augment, verbose)
+            except Exception as e:
+                print('Warning: batch inference failed for shape {}: {}'.format(shape, str(e)))
+                for original_idx, _, current_id in items:
+                    results[original_idx] = {'file': current_id, 'detections': None, 'failure': FAILURE_INFER}
+        return results
 
+    def _prepare_batch(self, img_original, image_id, image_size, verbose):
+        """per-image preprocessing with failure capture (reference :1194-1222) and grouping by processed
+        shape (:1226-1233); returns (results with the failed slots filled in, {shape: [(idx, info, id)]})"""
         results = [None] * len(img_original)
         preprocessed = []
         for i_img, img in enumerate(img_original):
@@ -204,29 +218,13 @@ class HIPDetector:
                 current_id = image_id[i_img] if image_id else 'index_{}'.format(i_img)
                 print('Warning: preprocessing failed for image {}: {}'.format(current_id, str(e)))
                 results[i_img] = {'file': current_id, 'detections': None, 'failure': FAILURE_IMAGE_OPEN}
-
         shape_groups = {}
         for item in preprocessed:
             shape_groups.setdefault(tuple(item[1]['img_processed'].shape), []).append(item)
+        return results, shape_groups
 
-        for shape, items in shape_groups.items():
-            try:
-                for start in range(0, len(items), self.max_batch):
-                    self._process_batch_group(items[start:start + self.max_batch], results,
-                                              detection_threshold, augment, verbose)
-            except Exception as e:
-                print('Warning: batch inference failed for shape {}: {}'.format(shape, str(e)))
-                for original_idx, _, current_id in items:
-                    results[original_idx] = {'file': current_id, 'detections': None, 'failure': FAILURE_INFER}
-        return results
-
-    def _process_batch_group(self, group_items, results, detection_threshold, augment, verbose):
-        """reference pytorch_detector.py:1257-1426 with the device work in libmdhip.so"""
-        if len(group_items) == 0:
-            return
-        if augment:
-            raise NotImplementedError('test-time augmentation is not implemented in the HIP path')
-        h, w = group_items[0][1]['img_processed'].shape[:2]
+    @staticmethod
+    def _group_inputs(group_items):
         images, geoms = [], []
         for _, info, _ in group_items:
             ip = info['img_processed']
@@ -237,12 +235,9 @@ class HIPDetector:
                 ip = np.ascontiguousarray(ip)
                 images.append(ip)
                 geoms.append((ip.shape[0], ip.shape[1], ip.shape[0], ip.shape[1], 0, 0))
-        n = len(group_items)
-        ctx = self._ctx
-        ctx.preprocess(images, geoms, h, w)
-        ctx.forward(n, h, w)
-        nms_iou_thres = 0.45            # 'classic' (reference :1318-1321)
-        det_all, counts = ctx.nms(n, detection_threshold, nms_iou_thres, max_det=300)
+        return images, geoms
+
+    def _format_group(self, group_items, det_all, counts, h, w, results, detection_threshold):
         for i, (original_idx, info, current_id) in enumerate(group_items):
             det = det_all[i, :counts[i]]
             detections, max_conf = format_detections(
@@ -250,6 +245,131 @@ class HIPDetector:
                 use_model_native_classes=self.use_model_native_classes)
             results[original_idx] = {'file': current_id, 'detections': detections,
                                      'max_detection_conf': max_conf}
+
+    def _process_batch_group(self, group_items, results, detection_threshold, augment, verbose):
+        """reference pytorch_detector.py:1257-1426 with the device work in libmdhip.so"""
+        if len(group_items) == 0:
+            return
+        if augment:
+            raise NotImplementedError('test-time augmentation is not implemented in the HIP path')
+        h, w = group_items[0][1]['img_processed'].shape[:2]
+        images, geoms = self._group_inputs(group_items)
+        n = len(group_items)
+        ctx = self._ctx
+        ctx.preprocess(images, geoms, h, w)
+        ctx.forward(n, h, w)
+        nms_iou_thres = 0.45            # 'classic' (reference :1318-1321)
+        det_all, counts = ctx.nms(n, detection_threshold, nms_iou_thres, max_det=300)
+        self._format_group(group_items, det_all, counts, h, w, results, detection_threshold)
+
+    # -----------------------------------------------------------------------------------
+    # Pipelined variant of generate_detections_one_batch for the batch driver (feed.py): the device work
+    # of a batch is enqueued on a private stream and the call returns; finish_batch() waits for it and
+    # formats.  Host images are copied to the device on a copy stream into one of two staging buffers
+    # (asynchronously when they live in page-locked memory, e.g. feed.SharedImageRing), so the copy of
+    # batch i+1 overlaps the kernels of batch i.  Same kernels, same results as the synchronous call.
+    # -----------------------------------------------------------------------------------
+    def _pipeline(self):
+        if getattr(self, '_pl', None) is None:
+            import torch
+            dev = torch.device('cuda', _device_ordinal(self.device))
+            with torch.cuda.device(dev):
+                self._pl = {'torch': torch, 'dev': dev, 'copy_s': torch.cuda.Stream(), 'comp_s': torch.cuda.Stream(),
+                            'stage': [None, None], 'copied': [torch.cuda.Event(), torch.cuda.Event()],
+                            'consumed': [None, None], 'count': 0}
+        return self._pl
+
+    def _submit_group(self, group_items, detection_threshold):
+        pl = self._pipeline()
+        torch = pl['torch']
+        h, w = group_items[0][1]['img_processed'].shape[:2]
+        images, geoms = self._group_inputs(group_items)
+        n = len(group_items)
+        k = pl['count'] % 2
+        nms_slot = pl['count'] % 4
+        pl['count'] += 1
+        offs, total = [], 0
+        for im in images:
+            offs.append(total)
+            total += (im.nbytes + 255) // 256 * 256
+        with torch.cuda.device(pl['dev']):
+            if pl['stage'][k] is None or pl['stage'][k].numel() < total:
+                if pl['consumed'][k] is not None:
+                    pl['consumed'][k].synchronize()
+                pl['stage'][k] = torch.empty(max(total, 1), dtype=torch.uint8, device=pl['dev'])
+            stage = pl['stage'][k]
+            with torch.cuda.stream(pl['copy_s']):
+                if pl['consumed'][k] is not None:
+                    pl['copy_s'].wait_event(pl['consumed'][k])      # the letterbox kernel that read this buffer is done
+                for im, off in zip(images, offs):
+                    flat = im.reshape(-1)
+                    if not flat.flags.writeable:          # torch warns on read-only arrays; the copy only reads
+                        flat = flat.view()
+                        try:
+                            flat.flags.writeable = True
+                        except ValueError:
+                            flat = np.array(flat)
+                    stage[off:off + im.nbytes].copy_(torch.from_numpy(flat), non_blocking=True)
+                pl['copied'][k].record(pl['copy_s'])
+            comp = pl['comp_s']
+            comp.wait_event(pl['copied'][k])
+            base = stage.data_ptr()
+            ctx = self._ctx
+            ctx.preprocess([base + off for off in offs], geoms, h, w, stream=comp.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(comp)
+            pl['consumed'][k] = ev
+            ctx.forward(n, h, w, stream=comp.cuda_stream)
+            ctx.nms_enqueue(n, detection_threshold, 0.45, 300, slot=nms_slot, stream=comp.cuda_stream)
+        return {'items': group_items, 'h': h, 'w': w, 'slot': nms_slot, 'copied': pl['copied'][k], 'images': images}
+
+    def _collect_group(self, handle, results, detection_threshold):
+        det_all, counts = self._ctx.nms_wait(slot=handle['slot'])
+        self._format_group(handle['items'], det_all, counts, handle['h'], handle['w'], results, detection_threshold)
+
+    def start_batch(self, img_original, image_id, detection_threshold=0.00001, image_size=None, verbose=False):
+        """Enqueues a batch; returns a ticket for finish_batch().  At most two tickets may be outstanding."""
+        if self._ctx is None:
+            raise RuntimeError('this HIPDetector was created with preprocess_only')
+        if detection_threshold is None:
+            detection_threshold = 0.0
+        results, shape_groups = self._prepare_batch(img_original, image_id, image_size, verbose)
+        chunks = []
+        for shape, items in shape_groups.items():
+            for start in range(0, len(items), self.max_batch):
+                chunks.append(items[start:start + self.max_batch])
+        pending = None
+        for ci, chunk in enumerate(chunks):
+            try:
+                handle = self._submit_group(chunk, detection_threshold)
+                if ci == len(chunks) - 1:
+                    pending = handle                     # the last group stays in flight
+                else:
+                    self._collect_group(handle, results, detection_threshold)
+            except Exception as e:
+                print('Warning: batch inference failed for shape {}: {}'.format(chunk[0][1]['img_processed'].shape, str(e)))
+                for original_idx, _, current_id in chunk:
+                    results[original_idx] = {'file': current_id, 'detections': None, 'failure': FAILURE_INFER}
+        return {'results': results, 'pending': pending, 'threshold': detection_threshold}
+
+    def batch_inputs_consumed(self, ticket):
+        """Blocks until the host images of the ticket's in-flight group have been copied to the device
+        (their buffers -- e.g. shared-ring slots -- may then be reused)."""
+        if ticket['pending'] is not None:
+            ticket['pending']['copied'].synchronize()
+
+    def finish_batch(self, ticket):
+        results = ticket['results']
+        handle = ticket['pending']
+        if handle is not None:
+            try:
+                self._collect_group(handle, results, ticket['threshold'])
+            except Exception as e:
+                print('Warning: batch inference failed: {}'.format(str(e)))
+                for original_idx, _, current_id in handle['items']:
+                    results[original_idx] = {'file': current_id, 'detections': None, 'failure': FAILURE_INFER}
+            ticket['pending'] = None
+        return results
 
     # -----------------------------------------------------------------------------------
     def generate_detections_one_image(self, img_original, image_id='unknown', detection_threshold=0.00001,

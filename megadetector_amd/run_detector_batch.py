@@ -14,9 +14,13 @@ New here (spec = reference notebooks/manage_local_batch.
                                 image list, host-side merge with duplicate/missing checks -- no
                                 collectives; output identical to the 1-GPU result.
 
-Loader workers are threads, never forked processes: a forked child of a process that has touched
-HIP is undefined behaviour (the reference forks before loading the model, run_detector_batch.py:
-545-557; `--use_threads_for_queue` :1814 is its safe variant and the only one offered here).
+Loader workers are threads (`use_threads_for_queue=True`, reference :1814) or *spawned* processes that
+decode into a page-locked shared-memory ring (`use_threads_for_queue=False`; feed.py, SURVEY.md 8(f)
+N1) -- never forked processes: a forked child of a process that has touched HIP is undefined behaviour
+(the reference forks before loading the model, run_detector_batch.py:545-557).  In both queue modes the
+batches go through the detector's pipelined start_batch / finish_batch when it has them (the GPU works
+on batch i while the host formats batch i-1 and assembles batch i+1); results are identical to the
+plain loop.
 """
 
 import argparse
@@ -30,7 +34,8 @@ import threading
 import time
 from datetime import datetime
 
-from . import run_detector
+from . import feed, run_detector
+from .feed import load_image, EXIF_IMAGE_ROTATIONS          # noqa: F401  (re-exported)
 from .constants import FAILURE_IMAGE_OPEN, FAILURE_INFER, DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD
 from .constants import DEFAULT_DETECTOR_LABEL_MAP
 
@@ -42,33 +47,11 @@ current_format_version = '1.6'
 verbose = False
 
 image_extensions = ('.jpg', '.jpeg', '.gif', '.png')           # reference ct_utils.py:30
-EXIF_IMAGE_ROTATIONS = {3: 180, 6: 270, 8: 90}                  # reference visualization_utils.py
 
 
 # --------------------------------------------------------------------------------------------
 # host I/O helpers
 # --------------------------------------------------------------------------------------------
-def load_image(input_file, ignore_exif_rotation=False):
-    """PIL decode to RGB with EXIF rotation (reference visualization_utils.py:103-175, :306)."""
-    from PIL import Image
-    image = Image.open(input_file)
-    if image.mode not in ('RGBA', 'RGB', 'L', 'I;16'):
-        raise AttributeError('Image {} uses unsupported mode {}'.format(input_file, image.mode))
-    if image.mode in ('RGBA', 'L'):
-        image = image.convert(mode='RGB')
-    if not ignore_exif_rotation:
-        try:
-            exif = image._getexif()
-            orientation = exif.get(274, None)
-            if orientation is not None and orientation != 1:
-                assert orientation in EXIF_IMAGE_ROTATIONS, 'Mirrored rotations are not supported'
-                image = image.rotate(EXIF_IMAGE_ROTATIONS[orientation], expand=True)
-        except Exception:
-            pass
-    image.load()
-    return image
-
-
 def is_image_file(s):
     return os.path.splitext(s)[1].lower() in image_extensions
 
@@ -141,6 +124,86 @@ def _add_image_metadata(result, image, include_image_size, include_image_timesta
         result['datetime'] = dt
 
 
+def _filter_batch_output(dets, names, images, confidence_threshold, include_image_size, include_image_timestamp):
+    """reference :760-792: the batched detector call gets no threshold; it is applied to its output"""
+    assert len(dets) == len(names)
+    out = []
+    for i, r in enumerate(dets):
+        assert names[i] == r['file']
+        if 'failure' not in r:
+            r['detections'] = [d for d in r['detections'] if d['conf'] >= confidence_threshold]
+            if include_image_size or include_image_timestamp:
+                _add_image_metadata(r, images[i], include_image_size, include_image_timestamp)
+        else:
+            print('Warning: within-batch processing failure for image {}'.format(r['file']))
+        out.append(r)
+    return out
+
+
+class _BatchPipeline:
+    """
+    Feeds batches of (file, image, meta_image, release) to the detector.  With a detector that has
+    start_batch / finish_batch (HIPDetector) two batches are kept in flight; otherwise every batch is
+    processed synchronously.  `release` (or None) is called once the detector no longer reads the pixels.
+    """
+
+    def __init__(self, detector, confidence_threshold, include_image_size, include_image_timestamp, on_results,
+                 depth=2):
+        self.det = detector
+        self.thr = confidence_threshold
+        self.inc_size, self.inc_time = include_image_size, include_image_timestamp
+        self.on_results = on_results
+        self.async_ok = hasattr(detector, 'start_batch') and hasattr(detector, 'finish_batch')
+        self.depth = depth
+        self.inflight = []
+
+    def submit(self, items):
+        if not items:
+            return
+        names = [it[0] for it in items]
+        images = [it[1] for it in items]
+        metas = [it[2] if it[2] is not None else it[1] for it in items]
+        releases = [it[3] for it in items if it[3] is not None]
+        if not self.async_ok:
+            try:
+                dets = self.det.generate_detections_one_batch(images, names, verbose=verbose)
+                res = _filter_batch_output(dets, names, metas, self.thr, self.inc_size, self.inc_time)
+            except Exception as e:
+                print('Batch processing failure for {} images: {}'.format(len(images), str(e)))
+                res = [{'file': n, 'failure': FAILURE_INFER} for n in names]
+            for r in releases:
+                r()
+            self.on_results(res)
+            return
+        try:
+            ticket = self.det.start_batch(images, names, verbose=verbose)
+        except Exception as e:
+            print('Batch processing failure for {} images: {}'.format(len(images), str(e)))
+            for r in releases:
+                r()
+            self.on_results([{'file': n, 'failure': FAILURE_INFER} for n in names])
+            return
+        self.inflight.append((ticket, names, metas, releases))
+        while len(self.inflight) >= self.depth:
+            self._finish_oldest()
+
+    def _finish_oldest(self):
+        ticket, names, metas, releases = self.inflight.pop(0)
+        try:
+            dets = self.det.finish_batch(ticket)
+            res = _filter_batch_output(dets, names, metas, self.thr, self.inc_size, self.inc_time)
+        except Exception as e:
+            print('Batch processing failure for {} images: {}'.format(len(names), str(e)))
+            res = [{'file': n, 'failure': FAILURE_INFER} for n in names]
+        for r in releases:
+            r()
+        self.on_results(res)
+
+    def drain(self):
+        while self.inflight:
+            self._finish_oldest()
+
+
 def _process_batch(image_items_batch, detector, confidence_threshold, quiet=False, image_size=None,
                    include_image_size=False, include_image_timestamp=False, include_exif_tags=None,
                    augment=False):
@@ -169,16 +232,8 @@ def _process_batch(image_items_batch, detector, confidence_threshold, quiet=Fals
     if valid_images:
         try:
             dets = detector.generate_detections_one_batch(valid_images, valid_names, verbose=verbose)
-            assert len(dets) == len(valid_images)
-            for i, r in enumerate(dets):
-                assert valid_names[i] == r['file']
-                if 'failure' not in r:
-                    r['detections'] = [d for d in r['detections'] if d['conf'] >= confidence_threshold]
-                    if include_image_size or include_image_timestamp:
-                        _add_image_metadata(r, valid_images[i], include_image_size, include_image_timestamp)
-                else:
-                    print('Warning: within-batch processing failure for image {}'.format(r['file']))
-                valid_results.append(r)
+            valid_results = _filter_batch_output(dets, valid_names, valid_images, confidence_threshold,
+                                                 include_image_size, include_image_timestamp)
         except Exception as e:
             print('Batch processing failure for {} images: {}'.format(len(valid_images), str(e)))
             valid_results = [{'file': n, 'failure': FAILURE_INFER} for n in valid_names]
@@ -278,12 +333,12 @@ def _run_detector_with_image_queue(image_files, detector, confidence_threshold, 
         t.start()
     finished = 0
     pending = []
+    pipe = _BatchPipeline(detector, confidence_threshold, include_image_size, include_image_timestamp, on_results)
 
     def flush():
         if pending:
             if batch_size > 1:
-                on_results(_process_batch(list(pending), detector, confidence_threshold, quiet, image_size,
-                                          include_image_size, include_image_timestamp, None, augment))
+                pipe.submit([(f, im, None, None) for f, im, _ in pending])
             else:
                 on_results([_process_image(f, detector, confidence_threshold, image=im, quiet=quiet,
                                            image_size=image_size, include_image_size=include_image_size,
@@ -303,8 +358,68 @@ def _run_detector_with_image_queue(image_files, detector, confidence_threshold, 
         if len(pending) >= max(1, batch_size):
             flush()
     flush()
+    pipe.drain()
     for t in threads:
         t.join()
+
+
+# the shared-memory ring: slot size (bytes) and slots per image of the batch size
+ring_slot_bytes = 48 * 1024 * 1024              # a 16-megapixel RGB frame; larger images travel through the queue
+ring_slots_per_batch_image = 3                  # one batch being filled, two in flight
+
+
+def _run_detector_with_shared_ring(image_files, detector, confidence_threshold, quiet, image_size,
+                                   include_image_size, include_image_timestamp, augment, loader_workers,
+                                   batch_size, on_results):
+    """
+    SURVEY.md 8(f) N1 (feed.py): spawned loader processes decode into a page-locked shared-memory ring,
+    the batches go through the detector's pipelined interface.  Same results as every other mode.
+    """
+    bs = max(1, batch_size)
+    n_workers = max(1, min(loader_workers, len(image_files)))
+    n_slots = ring_slots_per_batch_image * bs + n_workers
+    loader = feed.ProcessLoader(image_files, n_workers, n_slots, ring_slot_bytes,
+                                want_meta=include_image_size or include_image_timestamp)
+    ring = loader.ring
+    try:
+        if hasattr(detector, 'start_batch'):
+            ring.pin()
+        pipe = _BatchPipeline(detector, confidence_threshold, include_image_size, include_image_timestamp, on_results)
+        pending = []
+
+        def flush():
+            if not pending:
+                return
+            if bs > 1:
+                pipe.submit(list(pending))
+            else:
+                for f, im, meta_img, release in pending:
+                    r = _process_image(f, detector, confidence_threshold, image=im, quiet=quiet,
+                                       image_size=image_size, include_image_size=False,
+                                       include_image_timestamp=False, augment=augment)
+                    if r.get('failure') is None and meta_img is not None:
+                        _add_image_metadata(r, meta_img, include_image_size, include_image_timestamp)
+                    if release is not None:
+                        release()
+                    on_results([r])
+            pending.clear()
+
+        for kind, im_file, payload, shape, meta in loader:
+            if kind == 'fail':
+                on_results([{'file': im_file, 'failure': FAILURE_IMAGE_OPEN}])
+                continue
+            meta_img = feed.ImageMeta(meta) if meta is not None else None
+            if kind == 'slot':
+                slot = payload
+                pending.append((im_file, ring.view(slot, shape), meta_img, (lambda s=slot: ring.release(s))))
+            else:
+                pending.append((im_file, payload, meta_img, None))
+            if len(pending) >= bs:
+                flush()
+        flush()
+        pipe.drain()
+    finally:
+        loader.close()
 
 
 # --------------------------------------------------------------------------------------------
@@ -379,7 +494,11 @@ def load_and_run_detector_batch(model_file, image_file_names, checkpoint_path=No
             write_checkpoint(checkpoint_path, results)
             since_checkpoint[0] = 0
 
-    if use_image_queue:
+    if use_image_queue and not use_threads_for_queue and len(image_files) > 0:
+        _run_detector_with_shared_ring(image_files, detector, confidence_threshold, quiet, image_size,
+                                       include_image_size, include_image_timestamp, augment, loader_workers,
+                                       batch_size, on_results)
+    elif use_image_queue:
         _run_detector_with_image_queue(image_files, detector, confidence_threshold, quiet, image_size,
                                        include_image_size, include_image_timestamp, augment, loader_workers,
                                        preprocess_on_image_queue, batch_size, on_results)

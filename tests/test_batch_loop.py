@@ -95,6 +95,57 @@ def test_orchestration_modes_give_identical_results(image_dir):
             assert max(det.batches) <= kw['batch_size']
 
 
+def test_shared_memory_ring_loader_processes(image_dir, monkeypatch):
+    """SURVEY.md 8(f) N1 (megadetector_amd/feed.py): spawned loader processes decoding into the shared-memory
+    ring give the plain run's results -- batched and unbatched, with image size/timestamp metadata, with a
+    broken file, and with images that do not fit a ring slot (they travel through the queue instead)."""
+    root, names = image_dir
+    plain = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True,
+                                            include_image_size=True, include_image_timestamp=True)
+    assert any('width' in r for r in plain)
+    for kw in (dict(batch_size=4, loader_workers=3), dict(batch_size=1, loader_workers=2)):
+        got = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True,
+                                              use_image_queue=True, use_threads_for_queue=False,
+                                              include_image_size=True, include_image_timestamp=True, **kw)
+        assert _strip(got) == _strip(plain), kw
+    monkeypatch.setattr(RDB, 'ring_slot_bytes', 45 * 64 * 3)        # only the smaller images fit a slot
+    got = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True, batch_size=4,
+                                          use_image_queue=True, use_threads_for_queue=False, loader_workers=2,
+                                          include_image_size=True, include_image_timestamp=True)
+    assert _strip(got) == _strip(plain)
+
+
+class PipelinedStub(StubDetector):
+    """StubDetector with the start_batch / finish_batch interface of HIPDetector: results must not depend
+    on which interface the driver uses, and at most two tickets may be outstanding."""
+
+    def __init__(self):
+        super().__init__()
+        self.outstanding = 0
+        self.max_outstanding = 0
+
+    def start_batch(self, imgs, names, detection_threshold=1e-5, image_size=None, verbose=False):
+        self.outstanding += 1
+        self.max_outstanding = max(self.max_outstanding, self.outstanding)
+        # the pixels must stay valid until finish_batch: keep views, not copies
+        return {'imgs': imgs, 'names': names}
+
+    def finish_batch(self, ticket):
+        self.outstanding -= 1
+        return self.generate_detections_one_batch(ticket['imgs'], ticket['names'])
+
+
+def test_pipelined_detector_interface_gives_identical_results(image_dir):
+    root, names = image_dir
+    plain = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True)
+    for kw in (dict(use_threads_for_queue=True), dict(use_threads_for_queue=False)):
+        det = PipelinedStub()
+        got = RDB.load_and_run_detector_batch('stub', names, detector=det, quiet=True, batch_size=2,
+                                              use_image_queue=True, loader_workers=2, **kw)
+        assert _strip(got) == _strip(plain), kw
+        assert det.outstanding == 0 and 1 <= det.max_outstanding <= 2
+
+
 def test_threshold_applied_after_batched_detector(image_dir):
     root, names = image_dir
     res = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), batch_size=4,

@@ -619,7 +619,10 @@ def test_batch_driver_modes_identical_on_gpu(tmp_path):
         for d in r['detections']:
             assert d['category'] in ('1', '2', '3') and 0.0 <= d['conf'] <= 1.0 and len(d['bbox']) == 4
     for kw in (dict(batch_size=4), dict(use_image_queue=True), dict(use_image_queue=True, batch_size=3),
-               dict(use_image_queue=True, batch_size=3, preprocess_on_image_queue=True, loader_workers=2)):
+               dict(use_image_queue=True, batch_size=3, preprocess_on_image_queue=True, loader_workers=2),
+               # spawned loader processes + page-locked shared-memory ring + pipelined detector
+               dict(use_image_queue=True, use_threads_for_queue=False, batch_size=3, loader_workers=2),
+               dict(use_image_queue=True, use_threads_for_queue=False, batch_size=1, loader_workers=2)):
         assert run(**kw) == plain, kw
     out = tmp_path / 'out.json'
     RDB.write_results_to_file(plain, str(out), detector_file=model)
