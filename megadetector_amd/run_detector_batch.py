@@ -637,6 +637,9 @@ def main(argv=None):
     ap.add_argument('--augment', action='store_true')
     ap.add_argument('--use_image_queue', action='store_true')
     ap.add_argument('--preprocess_on_image_queue', action='store_true')
+    ap.add_argument('--use_threads_for_queue', action='store_true',
+                    help='loader threads instead of loader processes (reference :1814); without it the image queue '
+                         'uses spawned processes and the page-locked shared-memory ring (feed.py)')
     ap.add_argument('--loader_workers', type=int, default=default_loaders)
     ap.add_argument('--batch_size', type=int, default=1)
     ap.add_argument('--threshold', type=float, default=DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD)
@@ -668,7 +671,7 @@ def main(argv=None):
                   include_image_timestamp=args.include_image_timestamp, augment=args.augment,
                   detector_options=parse_kvp_list(args.detector_options), loader_workers=args.loader_workers,
                   preprocess_on_image_queue=args.preprocess_on_image_queue, batch_size=args.batch_size,
-                  verbose_output=args.verbose)
+                  verbose_output=args.verbose, use_threads_for_queue=args.use_threads_for_queue)
     t0 = time.time()
     if args.n_gpus > 1:
         results = run_sharded(args.detector_file, files, args.n_gpus, **kwargs)
