@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument('--model', default='YOLOV5X6_MD')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'],
                     help='storage type of activations and weights (bf16 = the BASELINE.json configuration)')
+    ap.add_argument('--no-table', action='store_true', help='ignore megadetector_amd/tuned_cfgs.json (heuristic tiles)')
     ap.add_argument('--src', default=None,
                     help='HxW of the source images (e.g. 1536x2048): the real-shape variant of SURVEY.md 8(d), '
                          'the letterbox kernel resizes to the --size long side; not the headline configuration')
@@ -116,6 +117,8 @@ def main():
     ctx = HipContext(weights, device=local_rank, dtype=args.dtype, max_batch=B, max_h=S, max_w=S)
 
     # measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json) are loaded by HipContext
+    if args.no_table:
+        ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
 
     # synthetic uint8 RGB batches, resident in HBM before the timed region
     n_batches = 4

@@ -620,24 +620,54 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             bool from_table = false;
             if (cfg < 0) {
                 const PackedConv& pc = ctx->packed[op.pc];
-                // The entry of the same layer geometry (N, K, taps, stride, residual) whose per-image M is
-                // equal or nearest within 4x (the same layer at another image shape, e.g. 960x1280 instead
-                // of 1280x1280), if that kernel takes this op.  Per image, not per call: the kernel family
-                // (= fp32 summation order) of an op must not depend on the batch size, or an image's
-                // result would depend on the batch it travels in.
-                double best = 1e30;
+                // 1. The canonical entry: same layer geometry (N, K, taps, stride, residual), per-image M equal
+                //    or nearest within 4x (the same layer at another image shape, e.g. 960x1280 instead of
+                //    1280x1280), largest batch among equals.  It fixes the kernel FAMILY (= fp32 summation
+                //    order) of the op -- per image, never per call, or an image's result would depend on the
+                //    batch it travels in.
+                // 2. Among the entries of that geometry, per-image M and family: the one measured at the
+                //    nearest total M (= nearest batch size).  Small batches want smaller tiles.
+                // 3. No entry within 4x of this call's total M: the fill-aware heuristic for the bitwise family,
+                //    the canonical configuration otherwise.
                 const double m_img = (double)a.M / n;
+                const mdhip_tuned* canon = nullptr;
+                double best = 1e30;
                 for (const mdhip_tuned& t : ctx->tuned) {
                     if (t.n != pc.c_out || t.k != pc.k_real || t.ntaps != a.ntaps || t.stride != a.stride ||
                         t.has_res != (op.has_res ? 1 : 0) || t.m <= 0)
                         continue;
-                    const double t_img = (double)t.m / (t.batch > 0 ? t.batch : 32);
+                    const int tb = t.batch > 0 ? t.batch : 32;
+                    const double t_img = (double)t.m / tb;
                     const double r = t_img > m_img ? t_img / m_img : m_img / t_img;
-                    if (r < best && r <= 4.0 && conv_api(ctx).supports(t.cfg, a)) {
+                    if (r > 4.0 || !conv_api(ctx).supports(t.cfg, a)) continue;
+                    const int cb = canon ? (canon->batch > 0 ? canon->batch : 32) : 0;
+                    if (r < best - 1e-9 || (r < best + 1e-9 && tb > cb)) {
                         best = r;
-                        cfg = t.cfg;
-                        from_table = true;
+                        canon = &t;
                     }
+                }
+                if (canon) {
+                    const bool fam = conv_cfg_is_bitwise_family(canon->cfg);
+                    const double c_img = (double)canon->m / (canon->batch > 0 ? canon->batch : 32);
+                    const mdhip_tuned* pick = nullptr;
+                    double best_m = 1e30;
+                    for (const mdhip_tuned& t : ctx->tuned) {
+                        if (t.n != canon->n || t.k != canon->k || t.ntaps != canon->ntaps || t.stride != canon->stride ||
+                            t.has_res != canon->has_res || t.m <= 0 || conv_cfg_is_bitwise_family(t.cfg) != fam)
+                            continue;
+                        const double t_img = (double)t.m / (t.batch > 0 ? t.batch : 32);
+                        if (t_img < c_img * 0.999 || t_img > c_img * 1.001 || !conv_api(ctx).supports(t.cfg, a)) continue;
+                        const double scaled = (double)t.m * (m_img / t_img);          // total M of that batch at this image shape
+                        const double r = scaled > a.M ? scaled / a.M : a.M / scaled;
+                        if (r < best_m) { best_m = r; pick = &t; }
+                    }
+                    if (pick && best_m <= 4.0) {
+                        cfg = pick->cfg;
+                        from_table = true;
+                    } else if (!fam) {
+                        cfg = canon->cfg;
+                        from_table = true;
+                    }                                   // else: heuristic below (bitwise family)
                 }
             }
             if (cfg < 0) cfg = choose_cfg(a.M, a.n_rows);

@@ -29,6 +29,10 @@ def main():
     ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'tuned_cfgs.json'))
     ap.add_argument('--table', default=None)
+    ap.add_argument('--family-from', default=None,
+                    help='existing table (measured at the canonical batch size): only configurations of the same kernel '
+                         'family (same fp32 summation order) as its entry for the layer are tried, so that an '
+                         'image\'s result does not depend on the batch size it is processed at')
     args = ap.parse_args()
 
     import torch
@@ -47,6 +51,12 @@ def main():
     lines = []
     cache = {}
     entries = {}
+    canon = {}
+    if args.family_from and os.path.exists(args.family_from):
+        for e in json.load(open(args.family_from)).get('entries', []):
+            key = (e['n'], e['k'], e['ntaps'], e['stride'], e['has_res'], e['m'] // max(1, e.get('batch', 32)))
+            if key not in canon or e.get('batch', 32) > canon[key][1]:
+                canon[key] = (bool(ctx.cfg_is_bitwise(e['cfg'])), e.get('batch', 32))
     for o in infos:
         if o['kind'] != 0:
             continue
@@ -55,7 +65,11 @@ def main():
             ms = cache[sig]
         else:
             ms = []
+            fam = canon.get((o['n'], o['k'], o['ntaps'], o['stride'], o['has_res'], o['m'] // B))
             for cfg in range(ncfg):
+                if fam is not None and bool(ctx.cfg_is_bitwise(cfg)) != fam[0]:
+                    ms.append(float('inf'))
+                    continue
                 try:
                     ctx.set_op_cfg(o['op'], cfg)
                     ms.append(min(ctx.time_op(o['op'], B, S, S, iters=args.iters) for _ in range(args.reps)))
