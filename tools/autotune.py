@@ -92,7 +92,7 @@ def main():
         except Exception:
             data = {'entries': []}
     keep = [e for e in data.get('entries', [])
-            if (e['m'], e['n'], e['k'], e['ntaps'], e['stride'], e['has_res']) not in entries]
+            if e.get('batch', 32) != B or (e['m'], e['n'], e['k'], e['ntaps'], e['stride'], e['has_res']) not in entries]
     data = {'n_cfgs': ncfg, 'entries': keep + list(entries.values())}
     json.dump(data, open(args.out, 'w'), indent=1, sort_keys=True)
     table = args.table or (os.path.splitext(args.out)[0] + '_{}_{}_{}.txt'.format(args.model, B, S))
