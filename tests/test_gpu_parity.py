@@ -629,3 +629,25 @@ def test_batch_driver_modes_identical_on_gpu(tmp_path):
     j = json.load(open(out))
     assert j['info']['format_version'] == '1.6' and len(j['images']) == len(names)
     assert j['detection_categories'] == {'1': 'animal', '2': 'person', '3': 'vehicle'}
+
+
+def test_video_frames_batched_equal_frame_by_frame_on_gpu():
+    """SURVEY.md 8(f) N2 (megadetector_amd/process_video.py): 11 frames of one shape through the HIP detector,
+    batched and pipelined, give exactly what the reference's one-frame-at-a-time callback loop gives."""
+    import json
+    from megadetector_amd import process_video as PV, run_detector
+    det = run_detector.load_detector('synthetic:YOLOV5N6_TEST:1', detector_options={'batch_size': 4, 'max_image_size': 320})
+    det.default_image_size = 320
+    frames = PU.structured_images(11, 180, 320, seed=91)
+    one = [det.generate_detections_one_image(f, PV.frame_number_to_filename(i), detection_threshold=1e-5)
+           for i, f in enumerate(frames) if i % 2 == 0]
+    got = PV.run_detector_on_frames(det, PV.ArrayFrameSource(frames, frame_rate=15.0), every_n_frames=2, batch_size=4,
+                                    detection_threshold=1e-5)
+    assert got['frame_filenames'] == [PV.frame_number_to_filename(i) for i in range(0, 11, 2)]
+    assert json.loads(json.dumps(got['results'])) == json.loads(json.dumps(one))
+    assert any(r['detections'] for r in got['results'])
+    md = PV.run_detector_on_videos(det, [('cam/clip.mp4', frames)], open_source=lambda fr: PV.ArrayFrameSource(fr, 15.0),
+                                   every_n_frames=2, batch_size=4, detection_threshold=1e-5)
+    im = PV.video_results_to_md_format(md)[0]
+    assert im['frames_processed'] == [0, 2, 4, 6, 8, 10] and im['frame_rate'] == 15.0
+    assert sum(len(r['detections']) for r in one) == len(im['detections'])
