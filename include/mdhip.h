@@ -113,6 +113,16 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
  * Leaves (n, n_anchors, 5+nc) fp32 predictions in a device buffer of the context. */
 int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream);
 
+/* Test-time augmentation: replaces mdhip_forward for `model(batch, augment=True)` (reference
+ * pytorch_detector.py:1313 -> yolov5 _forward_augment): three passes over the batch that mdhip_preprocess
+ * left in the context -- scale 1, scale 0.83 left-right flipped, scale 0.67 (bilinear, padded with 0.447 to
+ * the model stride) -- boxes de-scaled and un-flipped, the coarsest level of the first and the finest level of
+ * the last pass dropped, predictions concatenated.  mdhip_nms / mdhip_read_predictions then work on
+ * mdhip_last_num_anchors(ctx) anchors per image. */
+int mdhip_forward_tta(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream);
+/* anchors per image of the prediction the context currently holds (last forward, augmented forward or mdhip_nms_on) */
+int mdhip_last_num_anchors(mdhip_ctx* ctx);
+
 /* Replaces nms() (pytorch_detector.py:502-610) on the predictions of the last forward.
  * out: host, [n][max_det][6] = x1,y1,x2,y2,conf,cls in letterboxed pixels, sorted by
  * confidence (descending; ties by anchor index); counts: host, [n].  Blocks until the

@@ -62,6 +62,8 @@ SYMBOLS = {
     'mdhip_last_error': (C.c_char_p, [_P]),
     'mdhip_preprocess': (C.c_int, [_P, C.POINTER(_P), C.POINTER(mdhip_letterbox), C.c_int, C.c_int, C.c_int, _P]),
     'mdhip_forward': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    'mdhip_forward_tta': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    'mdhip_last_num_anchors': (C.c_int, [_P]),
     'mdhip_nms': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
     'mdhip_nms_enqueue': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _P]),
     'mdhip_nms_wait': (C.c_int, [_P, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_int32))]),

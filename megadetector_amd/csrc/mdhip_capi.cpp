@@ -85,6 +85,11 @@ struct mdhip_ctx {
     std::vector<PackedConv> packed;
     std::vector<Op> ops;
     Tensor input;                 // space-to-depth network input (16 channels, div 2)
+    Tensor input_orig;            // copy of it during test-time augmentation (the scaled passes overwrite `input`)
+    DecodeTta cur_tta;            // how the Detect decode of the running pass places its anchors
+    int cur_A = 0;                // anchors per image of the prediction being written (row pitch of `pred`)
+    int last_A = 0;               // anchors per image of the last forward (plain or augmented)
+    int a_cap = 0;                // capacity of `pred` and of the NMS scratch, anchors per image
     size_t arena_bytes = 0;
     char* arena = nullptr;
     char* warena = nullptr;       // packed weights + biases + zero page + anchors
@@ -321,6 +326,7 @@ struct Planner {
 
         // network input (space-to-depth, 16 channels)
         ctx->input = alloc(16, 2);
+        ctx->input_orig = alloc(16, 2);
 
         auto out_view = [&](int i) -> Tensor {
             const int tgt = concat_target[i];
@@ -709,12 +715,12 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
                 const int sl = (int)ctx->strides[l];
                 level_off += ctx->na * (h / sl) * (w / sl);
             }
-            const int A = num_anchors_for(ctx, h, w);
             op.bytes = (double)n * ny * nx * ctx->na * ctx->no * 8.0;
             HIP_TRY(ctx, launch_detect_decode((const float*)(ctx->arena + op.f32_off), op.f32_ld,
                                               (float*)(ctx->arena + ctx->pred_off), n, ny, nx, ctx->na,
-                                              ctx->no, A, level_off, ctx->strides[op.level],
-                                              (const float*)(ctx->warena + ctx->anchors_off) + op.level * ctx->na * 2, s));
+                                              ctx->no, ctx->cur_A, level_off, ctx->strides[op.level],
+                                              (const float*)(ctx->warena + ctx->anchors_off) + op.level * ctx->na * 2,
+                                              ctx->cur_tta, s));
             break;
         }
     }
@@ -796,9 +802,11 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     }
     // predictions, NMS scratch, letterbox geometry
     ctx->a_max = has_detect ? num_anchors_for(ctx, ctx->max_h, ctx->max_w) : 1;
-    ctx->pred_off = P.alloc_bytes((size_t)max_batch * ctx->a_max * ctx->no * 4);
+    // room for the concatenated predictions of test-time augmentation (three passes, <= 3 x a_max)
+    ctx->a_cap = has_detect ? 3 * ctx->a_max : 1;
+    ctx->pred_off = P.alloc_bytes((size_t)max_batch * ctx->a_cap * ctx->no * 4);
     size_t nms_kv[4];
-    for (int i = 0; i < 4; ++i) nms_kv[i] = P.alloc_bytes((size_t)max_batch * ctx->a_max * 4);
+    for (int i = 0; i < 4; ++i) nms_kv[i] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * 4);
     ctx->nms_out_off = P.alloc_bytes((size_t)max_batch * kNmsMaxDet * 6 * 4);
     ctx->nms_cnt_off = P.alloc_bytes((size_t)max_batch * 4);
     ctx->geom_off = P.alloc_bytes((size_t)max_batch * sizeof(LetterboxDev));
@@ -855,7 +863,7 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     ctx->nms_scr.keys[1] = (uint32_t*)(ctx->arena + nms_kv[1]);
     ctx->nms_scr.vals[0] = (uint32_t*)(ctx->arena + nms_kv[2]);
     ctx->nms_scr.vals[1] = (uint32_t*)(ctx->arena + nms_kv[3]);
-    ctx->nms_scr.cap = ctx->a_max;
+    ctx->nms_scr.cap = ctx->a_cap;
     CREATE_TRY(hipDeviceSynchronize());
 #undef CREATE_TRY
     *out = ctx;
@@ -952,6 +960,8 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int slot = (int)(ctx->fwd_count % mdhip_ctx::kFwdRing);
     if (ctx->time_forward) HIP_TRY(ctx, hipEventRecord(ctx->fwd_ev[slot][0], s));
+    ctx->cur_tta = DecodeTta();
+    ctx->cur_A = num_anchors_for(ctx, h, w);
     for (Op& op : ctx->ops)
         if (int rc = run_op(ctx, op, n, h, w, s)) return rc;
     if (ctx->time_forward) {
@@ -961,8 +971,70 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     ctx->last_n = n;
     ctx->last_h = h;
     ctx->last_w = w;
+    ctx->last_A = ctx->cur_A;
     return MDHIP_OK;
 }
+
+// yolov5 models/yolo.py:_forward_augment (what `model(batch, augment=True)` runs, reference
+// pytorch_detector.py:1313): three passes at scales 1 / 0.83 (left-right flipped) / 0.67 of the letterboxed
+// batch, boxes de-scaled and un-flipped, the largest-stride level of the first pass and the smallest-stride
+// level of the last pass dropped (_clip_augmented), predictions concatenated along the anchor axis.
+int mdhip_forward_tta(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
+    if (!ctx) return MDHIP_EINVAL;
+    if (int rc = check_shape(ctx, n, h, w)) return rc;
+    if (ctx->last_n < n || ctx->last_h != h || ctx->last_w != w)
+        return fail(ctx, MDHIP_EINVAL, "mdhip_forward_tta needs mdhip_preprocess of the same batch first");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const float scales[3] = {1.0f, 0.83f, 0.67f};
+    const double scales_d[3] = {1.0, 0.83, 0.67};
+    const int flips[3] = {0, 1, 0};
+    const int gs = ctx->max_stride;
+    int sh[3], sw[3], oh[3], ow[3], A[3];
+    for (int k = 0; k < 3; ++k) {
+        sh[k] = k ? (int)(h * scales_d[k]) : h;
+        sw[k] = k ? (int)(w * scales_d[k]) : w;
+        oh[k] = k ? (int)std::ceil(h * scales_d[k] / gs) * gs : h;
+        ow[k] = k ? (int)std::ceil(w * scales_d[k] / gs) * gs : w;
+        A[k] = num_anchors_for(ctx, oh[k], ow[k]);
+    }
+    long long g = 0, p4 = 1;
+    for (int l = 0; l < ctx->nl; ++l) { g += p4; if (l + 1 < ctx->nl) p4 *= 4; }      // p4 = 4^(nl-1)
+    const int i1 = (int)(A[0] / g), i3 = (int)((A[2] / g) * p4);
+    const int total = (A[0] - i1) + A[1] + (A[2] - i3);
+    if (total > ctx->a_cap || i1 >= A[0] || i3 >= A[2])
+        return fail(ctx, MDHIP_ENOMEM, "augmented prediction of %d anchors exceeds the planned %d", total, ctx->a_cap);
+    const size_t in_bytes = (size_t)n * (h / 2) * (w / 2) * 16 * 2;
+    uint16_t* in = (uint16_t*)(ctx->arena + ctx->input.off);
+    uint16_t* orig = (uint16_t*)(ctx->arena + ctx->input_orig.off);
+    HIP_TRY(ctx, hipMemcpyAsync(orig, in, in_bytes, hipMemcpyDeviceToDevice, s));
+    const int f16 = ctx->dtype == MDHIP_DTYPE_FP16;
+    ctx->cur_A = total;
+    int out_off = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (k) HIP_TRY(ctx, launch_tta_scale(orig, in, n, h, w, sh[k], sw[k], oh[k], ow[k], flips[k], f16, s));
+        DecodeTta t;
+        t.keep_from = k == 2 ? i3 : 0;
+        t.keep_to = k == 0 ? A[0] - i1 : A[k];
+        t.out_off = out_off;
+        t.scale = scales[k];
+        t.flip_lr = flips[k];
+        t.img_w = (float)w;
+        ctx->cur_tta = t;
+        for (Op& op : ctx->ops)
+            if (int rc = run_op(ctx, op, n, oh[k], ow[k], s)) return rc;
+        out_off += t.keep_to - t.keep_from;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(in, orig, in_bytes, hipMemcpyDeviceToDevice, s));       // `input` holds the batch again
+    ctx->cur_tta = DecodeTta();
+    ctx->last_n = n;
+    ctx->last_h = h;
+    ctx->last_w = w;
+    ctx->last_A = total;
+    return MDHIP_OK;
+}
+
+int mdhip_last_num_anchors(mdhip_ctx* ctx) { return ctx ? ctx->last_A : 0; }
 
 int mdhip_time_forwards(mdhip_ctx* ctx, int enable) {
     if (!ctx) return MDHIP_EINVAL;
@@ -1000,6 +1072,8 @@ int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hi
         ctx->events.push_back(ev);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->events[0], s));
+    ctx->cur_tta = DecodeTta();
+    ctx->cur_A = num_anchors_for(ctx, h, w);
     for (size_t i = 0; i < ctx->ops.size(); ++i) {
         if (int rc = run_op(ctx, ctx->ops[i], n, h, w, s)) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->events[i + 1], s));
@@ -1010,6 +1084,7 @@ int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hi
     ctx->last_n = n;
     ctx->last_h = h;
     ctx->last_w = w;
+    ctx->last_A = ctx->cur_A;
     return MDHIP_OK;
 }
 
@@ -1023,6 +1098,8 @@ int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float*
         HIP_TRY(ctx, hipEventCreate(&ev));
         ctx->events.push_back(ev);
     }
+    ctx->cur_tta = DecodeTta();
+    ctx->cur_A = num_anchors_for(ctx, h, w);
     if (int rc = run_op(ctx, ctx->ops[op], n, h, w, s)) return rc;    // warm
     HIP_TRY(ctx, hipEventRecord(ctx->events[0], s));
     for (int i = 0; i < iters; ++i)
@@ -1040,7 +1117,7 @@ static int nms_common(mdhip_ctx* ctx, const float* pred_dev, int n, int n_anchor
     if (!out || !counts) return fail(ctx, MDHIP_EINVAL, "out/counts is NULL");
     if (n < 1 || n > ctx->max_batch) return fail(ctx, MDHIP_EINVAL, "batch %d outside [1,%d]", n, ctx->max_batch);
     if (max_det < 1 || max_det > kNmsMaxDet) return fail(ctx, MDHIP_EINVAL, "max_det %d outside [1,%d]", max_det, kNmsMaxDet);
-    if (n_anchors < 1 || n_anchors > ctx->a_max) return fail(ctx, MDHIP_EINVAL, "n_anchors %d outside [1,%d]", n_anchors, ctx->a_max);
+    if (n_anchors < 1 || n_anchors > ctx->a_cap) return fail(ctx, MDHIP_EINVAL, "n_anchors %d outside [1,%d]", n_anchors, ctx->a_cap);
     float* out_dev = (float*)(ctx->arena + ctx->nms_out_off);
     int* cnt_dev = (int*)(ctx->arena + ctx->nms_cnt_off);
     HIP_TRY(ctx, launch_nms(pred_dev, n, n_anchors, ctx->no, conf_thres, iou_thres, max_det, ctx->nms_scr, out_dev, cnt_dev, s));
@@ -1055,7 +1132,7 @@ int mdhip_nms(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_
     if (!ctx) return MDHIP_EINVAL;
     if (ctx->last_h == 0) return fail(ctx, MDHIP_EINVAL, "mdhip_nms before mdhip_forward");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int A = num_anchors_for(ctx, ctx->last_h, ctx->last_w);
+    const int A = ctx->last_A;
     return nms_common(ctx, (const float*)(ctx->arena + ctx->pred_off), n, A, conf_thres, iou_thres,
                       max_det, out, counts, (hipStream_t)hip_stream);
 }
@@ -1069,7 +1146,7 @@ int mdhip_nms_enqueue(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, 
     if (max_det < 1 || max_det > kNmsMaxDet) return fail(ctx, MDHIP_EINVAL, "max_det %d outside [1,%d]", max_det, kNmsMaxDet);
     hipStream_t s = (hipStream_t)hip_stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int A = num_anchors_for(ctx, ctx->last_h, ctx->last_w);
+    const int A = ctx->last_A;
     float* out_dev = (float*)(ctx->arena + ctx->nms_out_off);
     int* cnt_dev = (int*)(ctx->arena + ctx->nms_cnt_off);
     HIP_TRY(ctx, launch_nms((const float*)(ctx->arena + ctx->pred_off), n, A, ctx->no, conf_thres, iou_thres, max_det,
@@ -1095,12 +1172,13 @@ int mdhip_nms_on(mdhip_ctx* ctx, const float* pred, int n, int n_anchors, float 
                  float iou_thres, int max_det, float* out, int32_t* counts, void* hip_stream) {
     if (!ctx) return MDHIP_EINVAL;
     if (!pred) return fail(ctx, MDHIP_EINVAL, "pred is NULL");
-    if (n < 1 || n > ctx->max_batch || n_anchors < 1 || n_anchors > ctx->a_max)
-        return fail(ctx, MDHIP_EINVAL, "n=%d n_anchors=%d outside the context capacity (%d x %d)", n, n_anchors, ctx->max_batch, ctx->a_max);
+    if (n < 1 || n > ctx->max_batch || n_anchors < 1 || n_anchors > ctx->a_cap)
+        return fail(ctx, MDHIP_EINVAL, "n=%d n_anchors=%d outside the context capacity (%d x %d)", n, n_anchors, ctx->max_batch, ctx->a_cap);
     hipStream_t s = (hipStream_t)hip_stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float* pred_dev = (float*)(ctx->arena + ctx->pred_off);
     HIP_TRY(ctx, hipMemcpyAsync(pred_dev, pred, (size_t)n * n_anchors * ctx->no * 4, hipMemcpyHostToDevice, s));
+    ctx->last_A = n_anchors;          // the context's prediction is now this tensor
     return nms_common(ctx, pred_dev, n, n_anchors, conf_thres, iou_thres, max_det, out, counts, s);
 }
 
@@ -1108,7 +1186,7 @@ int mdhip_read_predictions(mdhip_ctx* ctx, int n, float* out, void* hip_stream) 
     if (!ctx || !out) return MDHIP_EINVAL;
     if (ctx->last_h == 0 || n < 1 || n > ctx->last_n) return fail(ctx, MDHIP_EINVAL, "no forward result for n=%d", n);
     hipStream_t s = (hipStream_t)hip_stream;
-    const int A = num_anchors_for(ctx, ctx->last_h, ctx->last_w);
+    const int A = ctx->last_A;
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->arena + ctx->pred_off, (size_t)n * A * ctx->no * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return MDHIP_OK;

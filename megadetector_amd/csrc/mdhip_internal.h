@@ -178,10 +178,21 @@ hipError_t launch_upsample2x(const uint16_t* in, int ld_in, uint16_t* out, int l
 // strided channel-slice copy
 hipError_t launch_copy_view(const uint16_t* in, int ld_in, uint16_t* out, int ld_out, int c,
                             long long pixels, hipStream_t s);
-// Detect decode of one level: logits fp32 [n*ny*nx][ld] -> pred[n][n_anchors][no]
+// Detect decode of one level: logits fp32 [n*ny*nx][ld] -> pred[n][n_anchors][no].  A test-time-augmentation
+// pass keeps anchors [keep_from, keep_to) of its own numbering, de-scales / un-flips the boxes and writes them
+// at out_off of the concatenated prediction; the default is the plain forward.
+struct DecodeTta {
+    int keep_from = 0, keep_to = 0x7fffffff, out_off = 0;
+    float scale = 1.0f;
+    int flip_lr = 0;
+    float img_w = 0.f;
+};
 hipError_t launch_detect_decode(const float* logits, int ld, float* pred, int n, int ny, int nx,
                                 int na, int no, int n_anchors, int level_off, float stride,
-                                const float* anchors_px /*device, [na][2]*/, hipStream_t s);
+                                const float* anchors_px /*device, [na][2]*/, const DecodeTta& tta, hipStream_t s);
+// scale_img of yolov5's augmented inference: s2d input (h x w) -> s2d (oh x ow), bilinear to (sh x sw), pad 0.447
+hipError_t launch_tta_scale(const uint16_t* in, uint16_t* out, int n, int h, int w, int sh, int sw, int oh, int ow,
+                            int flip_lr, int f16, hipStream_t s);
 // debug readback: NHWC bf16 view -> NCHW fp32
 hipError_t launch_nhwc_to_nchw_f32(const uint16_t* in, int ld, float* out, int n, int c, int h,
                                    int w, int f16, hipStream_t s);

@@ -213,7 +213,7 @@ __device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + ex
 __global__ void __launch_bounds__(256)
 detect_decode_kernel(const float* __restrict__ logits, int ld, float* __restrict__ pred, int n,
                      int ny, int nx, int na, int no, int n_anchors, int level_off, float stride,
-                     const float* __restrict__ anchors_px) {
+                     const float* __restrict__ anchors_px, DecodeTta tta) {
     const long long total = (long long)n * na * ny * nx;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -221,24 +221,103 @@ detect_decode_kernel(const float* __restrict__ logits, int ld, float* __restrict
     const int y = (int)((t / nx) % ny);
     const int a = (int)((t / ((long long)nx * ny)) % na);
     const int b = (int)(t / ((long long)nx * ny * na));
+    // anchor index inside this forward pass; a test-time-augmentation pass keeps [keep_from, keep_to) of its
+    // anchors and appends them at out_off of the concatenated prediction (identity for a plain forward)
+    const int idx = level_off + (a * ny + y) * nx + x;
+    if (idx < tta.keep_from || idx >= tta.keep_to) return;
     const float* l = logits + ((size_t)(b * ny + y) * nx + x) * ld + a * no;
-    float* o = pred + ((size_t)b * n_anchors + level_off + (size_t)(a * ny + y) * nx + x) * no;
+    float* o = pred + ((size_t)b * n_anchors + tta.out_off + (idx - tta.keep_from)) * no;
     const float s0 = sigmoid_f32(l[0]), s1 = sigmoid_f32(l[1]);
     const float s2 = sigmoid_f32(l[2]), s3 = sigmoid_f32(l[3]);
-    o[0] = (s0 * 2.0f + ((float)x - 0.5f)) * stride;
-    o[1] = (s1 * 2.0f + ((float)y - 0.5f)) * stride;
+    float cx = (s0 * 2.0f + ((float)x - 0.5f)) * stride;
+    float cy = (s1 * 2.0f + ((float)y - 0.5f)) * stride;
     const float w2 = s2 * 2.0f, h2 = s3 * 2.0f;
-    o[2] = (w2 * w2) * anchors_px[a * 2 + 0];
-    o[3] = (h2 * h2) * anchors_px[a * 2 + 1];
+    float bw = (w2 * w2) * anchors_px[a * 2 + 0];
+    float bh = (h2 * h2) * anchors_px[a * 2 + 1];
+    if (tta.scale != 1.0f) {          // yolov5 _descale_pred: p[..., :4] /= scale, then un-flip
+        cx /= tta.scale; cy /= tta.scale; bw /= tta.scale; bh /= tta.scale;
+    }
+    if (tta.flip_lr) cx = tta.img_w - cx;
+    o[0] = cx; o[1] = cy; o[2] = bw; o[3] = bh;
     for (int i = 4; i < no; ++i) o[i] = sigmoid_f32(l[i]);
 }
 
 hipError_t launch_detect_decode(const float* logits, int ld, float* pred, int n, int ny, int nx,
                                 int na, int no, int n_anchors, int level_off, float stride,
-                                const float* anchors_px, hipStream_t s) {
+                                const float* anchors_px, const DecodeTta& tta, hipStream_t s) {
     const long long total = (long long)n * na * ny * nx;
     hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       logits, ld, pred, n, ny, nx, na, no, n_anchors, level_off, stride, anchors_px);
+                       logits, ld, pred, n, ny, nx, na, no, n_anchors, level_off, stride, anchors_px, tta);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// test-time augmentation input (yolov5 utils/torch_utils.py:scale_img on the optionally left-right
+// flipped batch): bilinear resize (torch F.interpolate, align_corners=False) of the normalised
+// network input to (sh, sw), padded with 0.447 to (oh, ow); space-to-depth in, space-to-depth out
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float s2d_load(const uint16_t* in, int b, int H2, int W2, int y, int x, int c, int f16) {
+    return st_to_f32(in[(((size_t)b * H2 + (y >> 1)) * W2 + (x >> 1)) * 16 + ((y & 1) * 2 + (x & 1)) * 3 + c], f16);
+}
+
+__global__ void __launch_bounds__(256)
+tta_scale_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int n, int h, int w, int sh, int sw,
+                 int oh, int ow, int flip_lr, int f16) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;     // s2d column of the output
+    const int Y = blockIdx.y;
+    const int b = blockIdx.z;
+    const int OW2 = ow >> 1, OH2 = oh >> 1;
+    if (X >= OW2) return;
+    const float ry = (float)h / (float)sh, rx = (float)w / (float)sw;
+    uint16_t px[16];
+#pragma unroll
+    for (int i = 12; i < 16; ++i) px[i] = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int y = 2 * Y + dy;
+        float fy = ry * ((float)y + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        const int y0 = (int)fy;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int x = 2 * X + dx;
+            float v[3] = {0.447f, 0.447f, 0.447f};
+            if (y < sh && x < sw) {
+                float fx = rx * ((float)x + 0.5f) - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const int x0 = (int)fx;
+                const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+                const int sx0 = flip_lr ? w - 1 - x0 : x0, sx1 = flip_lr ? w - 1 - x1 : x1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float p00 = s2d_load(in, b, h >> 1, w >> 1, y0, sx0, c, f16);
+                    const float p01 = s2d_load(in, b, h >> 1, w >> 1, y0, sx1, c, f16);
+                    const float p10 = s2d_load(in, b, h >> 1, w >> 1, y1, sx0, c, f16);
+                    const float p11 = s2d_load(in, b, h >> 1, w >> 1, y1, sx1, c, f16);
+                    v[c] = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[(dy * 2 + dx) * 3 + c] = f32_to_st(v[c], f16);
+        }
+    }
+    uint4* dst = (uint4*)(out + (((size_t)b * OH2 + Y) * OW2 + X) * 16);
+    uint4 lo, hi;
+    lo.x = px[0] | ((uint32_t)px[1] << 16);   lo.y = px[2] | ((uint32_t)px[3] << 16);
+    lo.z = px[4] | ((uint32_t)px[5] << 16);   lo.w = px[6] | ((uint32_t)px[7] << 16);
+    hi.x = px[8] | ((uint32_t)px[9] << 16);   hi.y = px[10] | ((uint32_t)px[11] << 16);
+    hi.z = px[12] | ((uint32_t)px[13] << 16); hi.w = px[14] | ((uint32_t)px[15] << 16);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
+hipError_t launch_tta_scale(const uint16_t* in, uint16_t* out, int n, int h, int w, int sh, int sw, int oh, int ow,
+                            int flip_lr, int f16, hipStream_t s) {
+    dim3 grid((ow / 2 + 255) / 256, oh / 2, n);
+    hipLaunchKernelGGL(tta_scale_kernel, grid, dim3(256), 0, s, in, out, n, h, w, sh, sw, oh, ow, flip_lr, f16);
     return hipGetLastError();
 }
 

@@ -14,9 +14,9 @@ Differences, all deliberate and documented in DESIGN.md:
     geometry; 'img_processed' is a LetterboxSpec placeholder exposing `.shape` (dicts carrying
     a real letterboxed ndarray, e.g. from the reference's own preprocessing workers, are
     accepted too);
-  * only compatibility_mode 'classic' (the reference default) is implemented;
-  * augment=True (TTA) is not implemented and raises, which the caller sees as
-    FAILURE_INFER for that batch, exactly like any other inference exception.
+  * only compatibility_mode 'classic' (the reference default) is implemented.
+augment=True runs yolov5's augmented inference (three scaled / flipped passes) on the device
+(mdhip_forward_tta).
 """
 
 import numpy as np
@@ -250,14 +250,15 @@ class HIPDetector:
         """reference pytorch_detector.py:1257-1426 with the device work in libmdhip.so"""
         if len(group_items) == 0:
             return
-        if augment:
-            raise NotImplementedError('test-time augmentation is not implemented in the HIP path')
         h, w = group_items[0][1]['img_processed'].shape[:2]
         images, geoms = self._group_inputs(group_items)
         n = len(group_items)
         ctx = self._ctx
         ctx.preprocess(images, geoms, h, w)
-        ctx.forward(n, h, w)
+        if augment:
+            ctx.forward_tta(n, h, w)        # yolov5 _forward_augment: 3 passes, concatenated predictions
+        else:
+            ctx.forward(n, h, w)
         nms_iou_thres = 0.45            # 'classic' (reference :1318-1321)
         det_all, counts = ctx.nms(n, detection_threshold, nms_iou_thres, max_det=300)
         self._format_group(group_items, det_all, counts, h, w, results, detection_threshold)

@@ -143,6 +143,13 @@ class HipContext:
     def forward(self, n, h, w, stream=0):
         self._check(self.lib.mdhip_forward(self.h, int(n), int(h), int(w), C.c_void_p(stream)), 'mdhip_forward')
 
+    def forward_tta(self, n, h, w, stream=0):
+        """augmented inference (yolov5 _forward_augment) on the batch left by preprocess()"""
+        self._check(self.lib.mdhip_forward_tta(self.h, int(n), int(h), int(w), C.c_void_p(stream)), 'mdhip_forward_tta')
+
+    def last_num_anchors(self):
+        return self.lib.mdhip_last_num_anchors(self.h)
+
     def nms(self, n, conf_thres, iou_thres, max_det=300, stream=0):
         out = np.empty((n, max_det, 6), dtype=np.float32)
         counts = np.empty((n,), dtype=np.int32)
@@ -183,8 +190,8 @@ class HipContext:
     def num_anchors(self, h, w):
         return self.lib.mdhip_num_anchors(self.h, int(h), int(w))
 
-    def read_predictions(self, n, h, w, stream=0):
-        out = np.empty((n, self.num_anchors(h, w), self.no), dtype=np.float32)
+    def read_predictions(self, n, h=None, w=None, stream=0):
+        out = np.empty((n, self.last_num_anchors(), self.no), dtype=np.float32)
         self._check(self.lib.mdhip_read_predictions(self.h, n, _lib.np_ptr(out), C.c_void_p(stream)),
                     'mdhip_read_predictions')
         return out

@@ -237,6 +237,60 @@ class Forward:
                 self.keep[L['i']] = x
         return x
 
+    # -- test-time augmentation -------------------------------------------------------
+    def forward_augment(self, x):
+        """
+        What `model(batch, augment=True)` computes (reference pytorch_detector.py:1313; the arithmetic lives
+        in ultralytics-yolov5 0.1.1 models/yolo.py `_forward_augment`, `_descale_pred`, `_clip_augmented`
+        and utils/torch_utils.py `scale_img`, restated here from their published behaviour): passes at
+        scales 1 / 0.83 / 0.67, the second on the left-right flipped batch; `scale_img` = bilinear
+        F.interpolate(align_corners=False) to (int(h*s), int(w*s)), padded right/bottom with 0.447 to a
+        multiple of the largest stride; boxes divided by the scale, x un-flipped against the original
+        width; the last (A//g) anchors of the first pass and the first (A//g)*4^(nl-1) anchors of the last
+        pass dropped, g = sum(4^l); concatenation along the anchor axis.  Parity unpinned (no yolov5 here).
+        """
+        import math
+        det = self.layers[-1]
+        nl = det['nl']
+        h, w = x.shape[2:]
+        gs = None
+        ys = []
+        if self.emulate:
+            x = self._round(x)
+        for si, flip in ((1.0, False), (0.83, True), (0.67, False)):
+            xi = x.flip(3) if flip else x
+            if si != 1.0:
+                sh, sw = int(h * si), int(w * si)
+                xi = F.interpolate(xi, size=(sh, sw), mode='bilinear', align_corners=False)
+                if gs is None:
+                    gs = self._max_stride()
+                oh, ow = (math.ceil(v * si / gs) * gs for v in (h, w))
+                xi = F.pad(xi, [0, ow - sw, 0, oh - sh], value=0.447)
+            yi = self(xi).clone()
+            yi[..., :4] /= si
+            if flip:
+                yi[..., 0] = w - yi[..., 0]
+            ys.append(yi)
+        g = sum(4 ** l for l in range(nl))
+        i = (ys[0].shape[1] // g) * 1
+        ys[0] = ys[0][:, :-i]
+        i = (ys[-1].shape[1] // g) * 4 ** (nl - 1)
+        ys[-1] = ys[-1][:, i:]
+        return torch.cat(ys, 1)
+
+    def _max_stride(self):
+        # strides of the Detect inputs, from the graph (every stride-2 conv doubles, every upsample halves)
+        div = []
+        for L in self.layers:
+            f = L['f'] if isinstance(L['f'], int) else L['f'][0]
+            d = 1 if (f == -1 and not div) else div[f if f >= 0 else len(div) + f]
+            if L['type'] == 'Conv':
+                d *= L['s']
+            elif L['type'] == 'nn.Upsample':
+                d //= 2
+            div.append(d)
+        return max(div[j] for j in self.layers[-1]['f'])
+
 
 # --------------------------------------------------------------------------------------
 # work accounting (used to pin the topology and by bench.py for the roofline)

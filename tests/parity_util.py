@@ -41,10 +41,10 @@ def oracle_input(images, image_size, stride):
     return O.to_batch_tensor([i['img_processed'] for i in infos]), infos
 
 
-def oracle_forward(weights, x, emulate_bf16, keep=None):
+def oracle_forward(weights, x, emulate_bf16, keep=None, augment=False):
     fw = Y.Forward(weights.yaml, weights.torch_state(), emulate_bf16=emulate_bf16, keep=keep)
     with torch.no_grad():
-        return fw(x), fw
+        return (fw.forward_augment(x) if augment else fw(x)), fw
 
 
 def rel_err(a, b):

@@ -651,3 +651,50 @@ def test_video_frames_batched_equal_frame_by_frame_on_gpu():
     im = PV.video_results_to_md_format(md)[0]
     assert im['frames_processed'] == [0, 2, 4, 6, 8, 10] and im['frame_rate'] == 15.0
     assert sum(len(r['detections']) for r in one) == len(im['detections'])
+
+
+def test_test_time_augmentation_matches_oracle(n6):
+    """
+    SURVEY.md 8(f) N3, `augment=True` (reference md_tests.py:917-930 exercises it): mdhip_forward_tta against the
+    oracle's restatement of yolov5 `_forward_augment` (bf16-emulating; parity unpinned, oracle/yolov5.py): anchor
+    count, the first pass bit-identical to the plain forward, de-scaled / un-flipped boxes and confidences of the
+    scaled passes within the layer tolerances, NMS on the concatenated predictions exact, and the detector
+    seam (`generate_detections_one_image(..., augment=True)`).
+    """
+    W, ctx = n6
+    hh, ww = 256, 320
+    imgs = PU.structured_images(2, hh, ww, seed=33)
+    ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+    ctx.forward(2, hh, ww)
+    plain = ctx.read_predictions(2).copy()
+    ctx.forward_tta(2, hh, ww)
+    got = ctx.read_predictions(2).copy()
+    x, infos = PU.oracle_input(imgs, 320, 64)
+    assert tuple(x.shape[2:]) == (hh, ww)
+    ref, _ = PU.oracle_forward(W, x, emulate_bf16=True, augment=True)
+    ref = ref.numpy()
+    assert got.shape == ref.shape and got.shape[1] == ctx.last_num_anchors() > plain.shape[1]
+    a1 = plain.shape[1] - plain.shape[1] // 85
+    np.testing.assert_array_equal(got[:, :a1], plain[:, :a1])                 # pass 1 = the plain forward
+    emax, emean = PU.rel_err(got[..., :4], ref[..., :4])
+    assert emax < 3e-2 and emean < 8e-3, (emax, emean)
+    assert np.abs(got[..., 4:] - ref[..., 4:]).max() < 3e-2
+    # flipped pass: box centres land inside the image again
+    assert got[..., 0].min() > -128 and got[..., 0].max() < ww + 128
+    out, counts = ctx.nms(2, 1e-5, 0.45, 300)
+    want = O.nms(torch.from_numpy(got), conf_thres=1e-5, iou_thres=0.45, max_det=300)
+    for i in range(2):
+        assert counts[i] == want[i].shape[0] > 0
+        np.testing.assert_array_equal(out[i, :counts[i]], want[i].numpy())
+    # the context still serves the plain path afterwards
+    ctx.forward(2, hh, ww)
+    np.testing.assert_array_equal(ctx.read_predictions(2), plain)
+    # through the detector seam
+    from megadetector_amd.detector import HIPDetector
+    det = HIPDetector(W, {'batch_size': 2, 'max_image_size': 320})
+    det.default_image_size = 320
+    r0 = det.generate_detections_one_image(imgs[0], 'a.jpg', detection_threshold=1e-5)
+    r1 = det.generate_detections_one_image(imgs[0], 'a.jpg', detection_threshold=1e-5, augment=True)
+    assert 'failure' not in r1 and r1['detections'] and r1 != r0
+    want1 = PU.oracle_detections(torch.from_numpy(det._ctx.read_predictions(1)), infos[:1], (hh, ww), 1e-5)[0]
+    assert r1['detections'] == want1['detections']
