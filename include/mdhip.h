@@ -88,8 +88,10 @@ typedef struct {
  * yolov5 letterbox() does (restated at pytorch_detector.py:434-454). */
 typedef struct {
     int32_t src_h, src_w;           /* original image                                   */
-    int32_t resized_h, resized_w;   /* new_unpad: size after cv2.resize(INTER_LINEAR)   */
+    int32_t resized_h, resized_w;   /* new_unpad: size after cv2.resize                  */
     int32_t top, left;              /* border offsets (copyMakeBorder, value 114)       */
+    int32_t interp;                 /* 0 = cv2.INTER_LINEAR (yolov5 letterbox; 'modern' growing),
+                                     * 1 = cv2.INTER_AREA ('modern' shrinking, pytorch_detector.py:1048-1062) */
 } mdhip_letterbox;
 
 typedef struct mdhip_ctx mdhip_ctx;

@@ -39,7 +39,7 @@ class mdhip_model(C.Structure):
 
 class mdhip_letterbox(C.Structure):
     _fields_ = [('src_h', C.c_int32), ('src_w', C.c_int32), ('resized_h', C.c_int32),
-                ('resized_w', C.c_int32), ('top', C.c_int32), ('left', C.c_int32)]
+                ('resized_w', C.c_int32), ('top', C.c_int32), ('left', C.c_int32), ('interp', C.c_int32)]
 
 
 class mdhip_op_info(C.Structure):

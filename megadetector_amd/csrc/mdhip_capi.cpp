@@ -919,7 +919,10 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
         else (void)hipGetLastError();
         on_host[i] = host;
         if (host) host_bytes += align_up((size_t)q.src_h * q.src_w * 3, 256);
-        g[i] = LetterboxDev{images[i], q.src_h, q.src_w, q.resized_h, q.resized_w, q.top, q.left};
+        if (q.interp != 0 && q.interp != 1) return fail(ctx, MDHIP_EINVAL, "image %d: interp %d (0 = linear, 1 = area)", i, q.interp);
+        if (q.interp == 1 && (q.resized_h > q.src_h || q.resized_w > q.src_w))
+            return fail(ctx, MDHIP_EINVAL, "image %d: INTER_AREA is implemented for shrinking only", i);
+        g[i] = LetterboxDev{images[i], q.src_h, q.src_w, q.resized_h, q.resized_w, q.top, q.left, q.interp};
     }
     if (host_bytes > ctx->stage_bytes) {
         HIP_TRY(ctx, hipStreamSynchronize(s));

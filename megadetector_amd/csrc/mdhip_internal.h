@@ -166,6 +166,7 @@ MDHIP_CONV_API
 struct LetterboxDev {     // device copy of mdhip_letterbox + source pointer
     const uint8_t* src;
     int src_h, src_w, resized_h, resized_w, top, left;
+    int interp;           // 0: cv2.INTER_LINEAR, 1: cv2.INTER_AREA (shrinking only)
 };
 // u8 HWC -> space-to-depth bf16 [n][out_h/2][out_w/2][16] (12 real channels: (dy,dx,c)), /255
 hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, int n, int out_h, int out_w,

@@ -35,6 +35,33 @@ __device__ __forceinline__ void linear_coef(int d, int dst_len, int src_len, int
     s1 = min(s + 1, src_len - 1);
 }
 
+// One axis of cv::computeResizeAreaTab (INTER_AREA, shrinking): destination index d covers source
+// [d*scale, (d+1)*scale); entries in accumulation order: optional left partial, whole cells, optional right partial.
+struct AreaAxis {
+    int s_left, s1, s2;          // left partial at s_left (if a_left >= 0), whole cells [s1, s2), right partial at s2
+    float a_left, a_mid, a_right; // weights; a_left / a_right < 0 when absent
+    __device__ int count() const { return (a_left >= 0.f) + (s2 - s1) + (a_right >= 0.f); }
+    __device__ void entry(int k, int& si, float& a) const {
+        if (a_left >= 0.f) { if (k == 0) { si = s_left; a = a_left; return; } --k; }
+        if (k < s2 - s1) { si = s1 + k; a = a_mid; return; }
+        si = s2; a = a_right;
+    }
+};
+__device__ __forceinline__ AreaAxis area_axis(int d, int dst_len, int src_len) {
+    const double scale = 1.0 / ((double)dst_len / (double)src_len);
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, (double)src_len - f1);
+    int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+    s2 = min(s2, src_len - 1);
+    s1 = min(s1, s2);
+    AreaAxis t;
+    t.s_left = s1 - 1; t.s1 = s1; t.s2 = s2;
+    t.a_left = ((double)s1 - f1 > 1e-3) ? (float)(((double)s1 - f1) / cell) : -1.f;
+    t.a_mid = (float)(1.0 / cell);
+    t.a_right = (f2 - (double)s2 > 1e-3) ? (float)(fmin(fmin(f2 - (double)s2, 1.0), cell) / cell) : -1.f;
+    return t;
+}
+
 __global__ void __launch_bounds__(256)
 letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w,
                      uint16_t* __restrict__ out, int f16) {
@@ -45,6 +72,15 @@ letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w
     if (X >= W2) return;
     const LetterboxDev g = geom[img];
     const bool resize = (g.resized_h != g.src_h) || (g.resized_w != g.src_w);
+    // INTER_AREA (compatibility_mode 'modern', shrinking): integer factors in both directions take OpenCV's
+    // integer path, everything else the float table path
+    const bool area = resize && g.interp == 1;
+    int isx = 0, isy = 0;
+    if (area) {
+        const double sx = 1.0 / ((double)g.resized_w / (double)g.src_w), sy = 1.0 / ((double)g.resized_h / (double)g.src_h);
+        const int rx = (int)rint(sx), ry = (int)rint(sy);
+        if (fabs(sx - rx) < 2.220446049250313e-16 && fabs(sy - ry) < 2.220446049250313e-16) { isx = rx; isy = ry; }
+    }
 
     uint16_t px[16];
 #pragma unroll
@@ -55,7 +91,7 @@ letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w
         const int y = 2 * Y + dy - g.top;
         int y0 = 0, y1 = 0, b0 = 2048, b1 = 0;
         const bool y_in = (unsigned)y < (unsigned)g.resized_h;
-        if (y_in && resize) linear_coef(y, g.resized_h, g.src_h, y0, y1, b0, b1);
+        if (y_in && resize && !area) linear_coef(y, g.resized_h, g.src_h, y0, y1, b0, b1);
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
             const int x = 2 * X + dx - g.left;
@@ -64,6 +100,43 @@ letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w
                 if (!resize) {
                     const uint8_t* s = g.src + ((size_t)y * g.src_w + x) * 3;
                     v[0] = s[0]; v[1] = s[1]; v[2] = s[2];
+                } else if (area && isx > 0) {
+                    // resizeAreaFast_: block sum; 2x2 as (s + 2) >> 2, else saturate_cast<uchar>(sum * (1.f / area))
+                    int sum[3] = {0, 0, 0};
+                    for (int yy = 0; yy < isy; ++yy) {
+                        const uint8_t* r = g.src + ((size_t)(y * isy + yy) * g.src_w + (size_t)x * isx) * 3;
+                        for (int xx = 0; xx < isx; ++xx) { sum[0] += r[xx * 3]; sum[1] += r[xx * 3 + 1]; sum[2] += r[xx * 3 + 2]; }
+                    }
+                    if (isx == 2 && isy == 2) {
+                        v[0] = (sum[0] + 2) >> 2; v[1] = (sum[1] + 2) >> 2; v[2] = (sum[2] + 2) >> 2;
+                    } else {
+                        const float sc = 1.0f / (float)(isx * isy);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) v[c] = min(max(__float2int_rn((float)sum[c] * sc), 0), 255);
+                    }
+                } else if (area) {
+                    // resizeArea_<uchar,float>: per source row buf = sum_k S[sx_k]*alpha_k, then sum = beta_0*buf_0,
+                    // sum += beta_j*buf_j; fp32 in table order; round half to even
+                    const AreaAxis ax = area_axis(x, g.resized_w, g.src_w), ay = area_axis(y, g.resized_h, g.src_h);
+                    const int nx = ax.count(), nyy = ay.count();
+                    float acc[3] = {0.f, 0.f, 0.f};
+                    for (int j = 0; j < nyy; ++j) {
+                        int sy; float beta;
+                        ay.entry(j, sy, beta);
+                        const uint8_t* r = g.src + (size_t)sy * g.src_w * 3;
+                        float buf[3] = {0.f, 0.f, 0.f};
+                        for (int k = 0; k < nx; ++k) {
+                            int sxk; float a;
+                            ax.entry(k, sxk, a);
+                            buf[0] = buf[0] + (float)r[sxk * 3] * a;
+                            buf[1] = buf[1] + (float)r[sxk * 3 + 1] * a;
+                            buf[2] = buf[2] + (float)r[sxk * 3 + 2] * a;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc[c] = j == 0 ? beta * buf[c] : acc[c] + beta * buf[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = min(max(__float2int_rn(acc[c]), 0), 255);
                 } else {
                     int x0, x1, a0, a1;
                     linear_coef(x, g.resized_w, g.src_w, x0, x1, a0, a1);

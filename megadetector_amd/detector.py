@@ -14,7 +14,8 @@ Differences, all deliberate and documented in DESIGN.md:
     geometry; 'img_processed' is a LetterboxSpec placeholder exposing `.shape` (dicts carrying
     a real letterboxed ndarray, e.g. from the reference's own preprocessing workers, are
     accepted too);
-  * only compatibility_mode 'classic' (the reference default) is implemented.
+  * in the non-classic compatibility modes the pre-resize (cv2.INTER_AREA / INTER_LINEAR to the long side) runs on
+    the GPU as well; 'img_original' stays the caller's array and 'resized_shape' carries the resized size.
 augment=True runs yolov5's augmented inference (three scaled / flipped passes) on the device
 (mdhip_forward_tta).
 """
@@ -23,7 +24,7 @@ import numpy as np
 
 from . import weights_io
 from .constants import (FAILURE_IMAGE_OPEN, FAILURE_INFER, DEFAULT_COMPATIBILITY_MODE)
-from .postprocess import letterbox_geometry, format_detections
+from .postprocess import letterbox_geometry, modern_geometry, format_detections
 
 
 def parse_bool_string(s):
@@ -74,8 +75,6 @@ class HIPDetector:
         preprocess_only = bool(opts.get('preprocess_only', False))
         if verbose or not preprocess_only:
             print('Loading HIP detector with compatibility mode {}'.format(compat))
-        if 'classic' not in compat:
-            raise ValueError('HIPDetector implements compatibility_mode "classic" only (got {})'.format(compat))
 
         self.model_metadata = None
         if isinstance(model_path, str) and not model_path.startswith('synthetic'):
@@ -124,6 +123,8 @@ class HIPDetector:
         self.max_batch = int(opts.get('batch_size', 1)) if int(opts.get('batch_size', 1)) > 1 else int(opts.get('max_batch', 8))
         max_size = int(opts.get('max_image_size', self.default_image_size))
         max_size = -(-max_size // weights.max_stride) * weights.max_stride
+        if 'classic' not in compat:
+            max_size += weights.max_stride      # the modern target shape is ceil(size / stride + 0.5) * stride
         self._ctx = HipContext(weights, device=_device_ordinal(device), dtype=opts.get('dtype', 'bf16'),
                                max_batch=self.max_batch, max_h=max_size, max_w=max_size)
         self.model = self._ctx
@@ -148,14 +149,27 @@ class HIPDetector:
         else:
             image_size = self.default_image_size
             self.printed_image_size_warning = False
-        g = letterbox_geometry(img_original.shape[:2], new_shape=image_size, stride=self.letterbox_stride,
-                               auto=True, scaleup=True)
-        geometry = (img_original.shape[0], img_original.shape[1], g['new_unpad'][1], g['new_unpad'][0],
-                    g['top'], g['left'])
+        if 'classic' in self.compatibility_mode:
+            g = letterbox_geometry(img_original.shape[:2], new_shape=image_size, stride=self.letterbox_stride,
+                                   auto=True, scaleup=True)
+            geometry = (img_original.shape[0], img_original.shape[1], g['new_unpad'][1], g['new_unpad'][0],
+                        g['top'], g['left'], 0)
+            target_shape = image_size
+        else:
+            # 'modern' (reference :1036-1101): resize to the long side (INTER_AREA when shrinking) and pad into the
+            # target shape -- both on the device; the reference replaces img_original by the resized image, here
+            # the pixels stay put and 'resized_shape' carries what the box rescaling needs
+            m = modern_geometry(img_original.shape[:2], image_size, self.letterbox_stride,
+                                use_ceil='use_ceil_for_resize' in self.compatibility_mode)
+            g = m['letterbox']
+            geometry = (img_original.shape[0], img_original.shape[1], m['resized_hw'][0], m['resized_hw'][1],
+                        g['top'], g['left'], m['interp'])
+            target_shape = m['target_shape']
+            result['resized_shape'] = (m['resized_hw'][0], m['resized_hw'][1], 3)
         result['img_processed'] = LetterboxSpec((g['out_hw'][0], g['out_hw'][1], 3), geometry)
         result['img_original'] = img_original
         result['img_original_pil'] = img_original_pil
-        result['target_shape'] = image_size
+        result['target_shape'] = target_shape
         result['scaling_shape'] = scaling_shape
         result['letterbox_ratio'] = g['ratio']
         result['letterbox_pad'] = g['pad']
@@ -223,6 +237,9 @@ class HIPDetector:
             shape_groups.setdefault(tuple(item[1]['img_processed'].shape), []).append(item)
         return results, shape_groups
 
+    def _nms_iou(self):
+        return 0.45 if 'classic' in self.compatibility_mode else 0.6        # reference :1318-1321
+
     @staticmethod
     def _group_inputs(group_items):
         images, geoms = [], []
@@ -240,9 +257,12 @@ class HIPDetector:
     def _format_group(self, group_items, det_all, counts, h, w, results, detection_threshold):
         for i, (original_idx, info, current_id) in enumerate(group_items):
             det = det_all[i, :counts[i]]
+            modern = 'classic' not in self.compatibility_mode
             detections, max_conf = format_detections(
-                det, (h, w), info['img_original'].shape, info['scaling_shape'], detection_threshold,
-                use_model_native_classes=self.use_model_native_classes)
+                det, (h, w), info.get('resized_shape', info['img_original'].shape) if modern else info['img_original'].shape,
+                info['scaling_shape'], detection_threshold,
+                use_model_native_classes=self.use_model_native_classes, modern=modern,
+                letterbox_pad=info.get('letterbox_pad'))
             results[original_idx] = {'file': current_id, 'detections': detections,
                                      'max_detection_conf': max_conf}
 
@@ -259,8 +279,7 @@ class HIPDetector:
             ctx.forward_tta(n, h, w)        # yolov5 _forward_augment: 3 passes, concatenated predictions
         else:
             ctx.forward(n, h, w)
-        nms_iou_thres = 0.45            # 'classic' (reference :1318-1321)
-        det_all, counts = ctx.nms(n, detection_threshold, nms_iou_thres, max_det=300)
+        det_all, counts = ctx.nms(n, detection_threshold, self._nms_iou(), max_det=300)
         self._format_group(group_items, det_all, counts, h, w, results, detection_threshold)
 
     # -----------------------------------------------------------------------------------
@@ -321,7 +340,7 @@ class HIPDetector:
             ev.record(comp)
             pl['consumed'][k] = ev
             ctx.forward(n, h, w, stream=comp.cuda_stream)
-            ctx.nms_enqueue(n, detection_threshold, 0.45, 300, slot=nms_slot, stream=comp.cuda_stream)
+            ctx.nms_enqueue(n, detection_threshold, self._nms_iou(), 300, slot=nms_slot, stream=comp.cuda_stream)
         return {'items': group_items, 'h': h, 'w': w, 'slot': nms_slot, 'copied': pl['copied'][k], 'images': images}
 
     def _collect_group(self, handle, results, detection_threshold):

@@ -120,7 +120,8 @@ class HipContext:
     def preprocess(self, images, geoms, out_h, out_w, stream=0):
         """
         images: list of HWC uint8 RGB numpy arrays (host) or integer device pointers.
-        geoms:  list of (src_h, src_w, resized_h, resized_w, top, left).
+        geoms:  list of (src_h, src_w, resized_h, resized_w, top, left[, interp]); interp 0 = cv2.INTER_LINEAR
+                (default), 1 = cv2.INTER_AREA.
         """
         n = len(images)
         ptrs = (C.c_void_p * n)()
@@ -136,7 +137,8 @@ class HipContext:
                 ptrs[i] = int(im)
         g = (_lib.mdhip_letterbox * n)()
         for i, q in enumerate(geoms):
-            g[i].src_h, g[i].src_w, g[i].resized_h, g[i].resized_w, g[i].top, g[i].left = [int(v) for v in q]
+            g[i].src_h, g[i].src_w, g[i].resized_h, g[i].resized_w, g[i].top, g[i].left = [int(v) for v in q[:6]]
+            g[i].interp = int(q[6]) if len(q) > 6 else 0
         self._check(self.lib.mdhip_preprocess(self.h, C.cast(ptrs, C.POINTER(C.c_void_p)), g, n, int(out_h), int(out_w),
                                               C.c_void_p(stream)), 'mdhip_preprocess')
 

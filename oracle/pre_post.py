@@ -117,6 +117,73 @@ def resize_linear_u8(img, dst_w, dst_h):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
+def area_tab(ssize, dsize):
+    """
+    cv::computeResizeAreaTab (OpenCV imgproc/resize.cpp) for one axis: per destination index the list of
+    (source index, float32 weight) in the order the kernel accumulates them.  scale is the double
+    1 / (dsize / ssize) of cv::resize.
+    """
+    scale = 1.0 / (float(dsize) / float(ssize))
+    tab = []
+    for d in range(dsize):
+        fsx1 = d * scale
+        fsx2 = fsx1 + scale
+        cell = min(scale, ssize - fsx1)
+        sx1, sx2 = int(math.ceil(fsx1)), int(math.floor(fsx2))
+        sx2 = min(sx2, ssize - 1)
+        sx1 = min(sx1, sx2)
+        ent = []
+        if sx1 - fsx1 > 1e-3:
+            ent.append((sx1 - 1, np.float32((sx1 - fsx1) / cell)))
+        for sx in range(sx1, sx2):
+            ent.append((sx, np.float32(1.0 / cell)))
+        if fsx2 - sx2 > 1e-3:
+            ent.append((sx2, np.float32(min(min(fsx2 - sx2, 1.0), cell) / cell)))
+        tab.append(ent)
+    return tab, scale
+
+
+def resize_area_u8(img, dst_w, dst_h):
+    """
+    cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_AREA) for HxWx3 uint8 when shrinking in both
+    directions (the only case the reference uses it for, pytorch_detector.py:1048-1062).  Integer scale
+    factors take OpenCV's integer path (resizeAreaFast_: block sum, 2x2 as (s+2)>>2, else
+    saturate_cast<uchar>(sum * (1.f/area))); everything else resizeArea_<uchar,float>: per source row
+    buf[dx] = sum_k S[sx_k]*alpha_k (fp32, in table order), then sum[dx] = beta0*buf0, += beta_j*buf_j,
+    output saturate_cast<uchar>(sum) = round-half-even.  PARITY UNPINNED (no OpenCV offline).
+    """
+    assert img.dtype == np.uint8 and img.ndim == 3
+    src_h, src_w = img.shape[:2]
+    assert dst_w <= src_w and dst_h <= src_h
+    xtab, sx = area_tab(src_w, dst_w)
+    ytab, sy = area_tab(src_h, dst_h)
+    isx, isy = int(np.rint(sx)), int(np.rint(sy))
+    if abs(sx - isx) < np.finfo(np.float64).eps and abs(sy - isy) < np.finfo(np.float64).eps:
+        blocks = img[:dst_h * isy, :dst_w * isx].astype(np.int64).reshape(dst_h, isy, dst_w, isx, 3).sum(axis=(1, 3))
+        if isx == 2 and isy == 2:
+            return ((blocks + 2) >> 2).astype(np.uint8)
+        scale = np.float32(1.0) / np.float32(isx * isy)
+        return np.clip(np.rint(blocks.astype(np.float32) * scale), 0, 255).astype(np.uint8)
+    src = img.astype(np.float32)
+    buf = np.zeros((src_h, dst_w, 3), dtype=np.float32)
+    for dx, ent in enumerate(xtab):
+        acc = np.zeros((src_h, 3), dtype=np.float32)
+        for sxk, a in ent:
+            acc = acc + src[:, sxk, :] * a
+        buf[:, dx, :] = acc
+    out = np.zeros((dst_h, dst_w, 3), dtype=np.float32)
+    for dy, ent in enumerate(ytab):
+        first = True
+        for syk, b in ent:
+            if first:
+                acc = b * buf[syk]
+                first = False
+            else:
+                acc = acc + b * buf[syk]
+        out[dy] = acc
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
 # --------------------------------------------------------------------------------------
 # letterbox  [3P: yolov5 utils/augmentations.py; ratio/pad arithmetic restated in-tree at
 # reference pytorch_detector.py:434-454]
@@ -166,6 +233,44 @@ def preprocess_image_classic(img_original, image_size=1280, stride=64):
                                 auto=True, scaleup=True)
     return dict(img_processed=img, img_original=img_original, target_shape=image_size,
                 scaling_shape=img_original.shape, letterbox_ratio=ratio, letterbox_pad=pad)
+
+
+def modern_geometry(shape_hw, image_size=1280, stride=64, use_ceil=False):
+    """
+    reference pytorch_detector.py:1036-1109, compatibility_mode 'modern': resized shape (long side -> image_size;
+    int() or ceil()), interpolation ('linear' when growing, 'area' when shrinking, None when the ratio is 1),
+    target shape ceil(normalised * image_size / stride + 0.5) * stride, and the letterbox of the RESIZED image
+    into it (auto=False, scaleup=False: padding only).
+    """
+    h, w = int(shape_hw[0]), int(shape_hw[1])
+    ratio = image_size / max(h, w)
+    rh, rw, interp = h, w, None
+    if ratio != 1:
+        interp = 'linear' if ratio > 1 else 'area'
+        rw = math.ceil(w * ratio) if use_ceil else int(w * ratio)
+        rh = math.ceil(h * ratio) if use_ceil else int(h * ratio)
+    md = max(rh, rw, 3)                    # max(img_original.shape) includes the channel count
+    norm = np.array([rh / md, rw / md])
+    target = (np.ceil((norm * image_size) / stride + 0.5).astype(int) * stride)
+    g = letterbox_geometry((rh, rw), new_shape=(int(target[0]), int(target[1])), stride=stride, auto=False, scaleup=False)
+    return dict(resized_hw=(rh, rw), interp=interp, target_shape=(int(target[0]), int(target[1])), letterbox=g)
+
+
+def preprocess_image_modern(img_original, image_size=1280, stride=64, use_ceil=False):
+    """reference pytorch_detector.py:964-1119 with a compatibility_mode other than 'classic'."""
+    img_original = np.asarray(img_original)
+    scaling_shape = img_original.shape
+    m = modern_geometry(img_original.shape[:2], image_size, stride, use_ceil)
+    rh, rw = m['resized_hw']
+    if m['interp'] == 'linear':
+        img_resized = resize_linear_u8(img_original, rw, rh)
+    elif m['interp'] == 'area':
+        img_resized = resize_area_u8(img_original, rw, rh)
+    else:
+        img_resized = img_original
+    img, ratio, pad = letterbox(img_resized, new_shape=m['target_shape'], stride=stride, auto=False, scaleup=False)
+    return dict(img_processed=img, img_original=img_resized, target_shape=m['target_shape'],
+                scaling_shape=scaling_shape, letterbox_ratio=ratio, letterbox_pad=pad)
 
 
 def to_batch_tensor(imgs_processed):
@@ -303,25 +408,48 @@ def xyxy2xywh(x):
     return y
 
 
+def scale_coords_ratio_pad(coords, img0_shape, ratio_pad):
+    """[3P] yolov5 utils/general.py:scale_coords with ratio_pad given: gain = ratio_pad[0][0], pad = ratio_pad[1]."""
+    gain = ratio_pad[0][0]
+    pad = ratio_pad[1]
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    coords[:, 0].clamp_(0, img0_shape[1])
+    coords[:, 1].clamp_(0, img0_shape[0])
+    coords[:, 2].clamp_(0, img0_shape[1])
+    coords[:, 3].clamp_(0, img0_shape[0])
+    return coords
+
+
 def format_detections(det, batch_hw, img_original_shape, scaling_shape, detection_threshold,
-                      use_model_native_classes=False):
+                      use_model_native_classes=False, modern=False, letterbox_pad=None):
     """
-    reference pytorch_detector.py:1361-1422, 'classic' branch.  det: (n,6) fp32 tensor from nms().
-    Returns (detections list, max_conf).
+    reference pytorch_detector.py:1361-1422.  det: (n,6) fp32 tensor from nms().  'classic' (default):
+    scale_coords against the image shape, truncation; modern: ratio_pad = ((resized/original per axis),
+    letterbox_pad), rounding instead of truncation.  Returns (detections list, max_conf).
     """
     detections = []
     max_conf = 0.0
     if len(det) > 0:
         det = det.clone()
         gn = torch.tensor(scaling_shape)[[1, 0, 1, 0]]
-        det[:, :4] = scale_coords(batch_hw, det[:, :4], img_original_shape).round()
+        if modern:
+            ratio = (img_original_shape[0] / scaling_shape[0], img_original_shape[1] / scaling_shape[1])
+            det[:, :4] = scale_coords_ratio_pad(det[:, :4], scaling_shape, (ratio, letterbox_pad)).round()
+        else:
+            det[:, :4] = scale_coords(batch_hw, det[:, :4], img_original_shape).round()
         for *xyxy, conf, cls in reversed(det):
             if conf < detection_threshold:
                 continue
             xywh = (xyxy2xywh(torch.tensor(xyxy).view(1, 4)) / gn).view(-1).tolist()
             api_box = convert_yolo_to_xywh(xywh)
-            api_box = truncate_float_array(api_box, precision=COORD_DIGITS)
-            conf = truncate_float(conf.tolist(), precision=CONF_DIGITS)
+            if modern:
+                api_box = round_float_array(api_box, precision=COORD_DIGITS)
+                conf = round_float(conf.tolist(), precision=CONF_DIGITS)
+            else:
+                api_box = truncate_float_array(api_box, precision=COORD_DIGITS)
+                conf = truncate_float(conf.tolist(), precision=CONF_DIGITS)
             if not use_model_native_classes:
                 cls = int(cls.tolist()) + 1
                 if cls not in (1, 2, 3):

@@ -55,7 +55,7 @@ def test_preprocess_only_instance_never_touches_hip_and_pickles():
         g = O.letterbox_geometry(shape, 1280, 64)
         assert r['img_processed'].shape == g['out_hw'] + (3,)
         assert r['letterbox_ratio'] == g['ratio'] and r['letterbox_pad'] == g['pad']
-        assert r['img_processed'].geometry == (shape[0], shape[1], g['new_unpad'][1], g['new_unpad'][0], g['top'], g['left'])
+        assert r['img_processed'].geometry == (shape[0], shape[1], g['new_unpad'][1], g['new_unpad'][0], g['top'], g['left'], 0)
         assert r['scaling_shape'] == img.shape and r['target_shape'] == 1280
         rr = pickle.loads(pickle.dumps(r))
         assert rr['img_processed'].shape == r['img_processed'].shape

@@ -698,3 +698,50 @@ def test_test_time_augmentation_matches_oracle(n6):
     assert 'failure' not in r1 and r1['detections'] and r1 != r0
     want1 = PU.oracle_detections(torch.from_numpy(det._ctx.read_predictions(1)), infos[:1], (hh, ww), 1e-5)[0]
     assert r1['detections'] == want1['detections']
+
+
+@pytest.mark.parametrize('shape', [(300, 400), (512, 384), (97, 211), (640, 640), (1000, 750), (256, 256), (150, 260)])
+def test_modern_mode_preprocess_bit_exact(n6, shape):
+    """compatibility_mode 'modern' (reference pytorch_detector.py:1036-1109): INTER_AREA / INTER_LINEAR resize to the
+    long side + centred padding into the modern target shape, on the device, against the oracle's restatement
+    (integer and fractional shrink factors, growing, no resize)."""
+    from megadetector_amd.postprocess import modern_geometry
+    W, ctx = n6
+    size = 256
+    imgs = PU.structured_images(2, shape[0], shape[1], seed=shape[1])
+    m = modern_geometry(shape, image_size=size, stride=64)
+    g = m['letterbox']
+    h, w = g['out_hw']
+    assert (h, w) == m['target_shape']
+    geoms = [(shape[0], shape[1], m['resized_hw'][0], m['resized_hw'][1], g['top'], g['left'], m['interp'])] * 2
+    ctx.preprocess(imgs, geoms, h, w)
+    got = ctx.read_input(2, h, w)
+    ref = [O.preprocess_image_modern(im, image_size=size, stride=64)['img_processed'] for im in imgs]
+    assert ref[0].shape[:2] == (h, w)
+    np.testing.assert_array_equal(got, PU.bf16_round_np(O.to_batch_tensor(ref).numpy()))
+
+
+def test_modern_mode_through_the_detector():
+    """detector with compatibility_mode='modern': NMS IoU 0.6, ratio_pad rescale, rounding -- detections equal the
+    oracle's modern post-processing applied to the HIP predictions; and they differ from classic (md_tests.py:1333)."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.detector import HIPDetector
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5N6_TEST, seed=1)
+    img = PU.structured_images(1, 450, 600, seed=77)[0]
+    res = {}
+    for mode in ('classic', 'modern'):
+        det = HIPDetector(W, {'batch_size': 2, 'max_image_size': 320, 'compatibility_mode': mode})
+        det.default_image_size = 320
+        res[mode] = det.generate_detections_one_image(img, 'a.jpg', detection_threshold=1e-5)
+        assert 'failure' not in res[mode] and res[mode]['detections']
+        if mode == 'modern':
+            info = O.preprocess_image_modern(img, image_size=320, stride=64)
+            hh, ww = info['img_processed'].shape[:2]
+            assert (hh, ww) == (320, 384)
+            pred = torch.from_numpy(det._ctx.read_predictions(1))
+            d = O.nms(pred, conf_thres=1e-5, iou_thres=0.6, max_det=300)[0]
+            want, want_max = O.format_detections(d, (hh, ww), info['img_original'].shape, info['scaling_shape'], 1e-5,
+                                                 modern=True, letterbox_pad=info['letterbox_pad'])
+            assert res[mode]['detections'] == want and res[mode]['max_detection_conf'] == want_max
+        det._ctx.close()
+    assert res['classic']['detections'] != res['modern']['detections']
