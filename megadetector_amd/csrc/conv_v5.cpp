@@ -461,11 +461,12 @@ conv_v5_kernel(const ConvArgs p) {
 #define MDHIP_CONV5_CFGS(X) \
     X(0, 128, 160, 2, 2, 0) \
     X(1, 128, 80, 4, 1, 0)  \
-    X(2, 256, 160, 4, 2, 0)
+    X(2, 256, 160, 4, 2, 0) \
+    X(3, 192, 80, 4, 1, 0)
 #define MDHIP_CONV5_PROF(X)  \
-    X(3, 128, 160, 2, 2, 1)  \
-    X(4, 128, 160, 2, 2, 16) \
-    X(5, 128, 160, 2, 2, 22)
+    X(4, 128, 160, 2, 2, 1)  \
+    X(5, 128, 160, 2, 2, 16) \
+    X(6, 128, 160, 2, 2, 22)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
