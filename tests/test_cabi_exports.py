@@ -84,3 +84,25 @@ def test_postprocess_matches_reference_statements():
     bad = np.array([[0, 0, 10, 10, 0.9, 7]], dtype=np.float32)
     with pytest.raises(KeyError):
         format_detections(bad, (64, 64), (64, 64, 3), (64, 64, 3), 0.1)
+
+
+def test_detector_input_validation_without_gpu():
+    """reference pytorch_detector.py:1155-1182: an empty batch is an empty result; mixed / mismatched inputs are
+    ValueErrors before anything touches the device"""
+    from megadetector_amd.detector import HIPDetector
+    det = HIPDetector('synthetic', {'preprocess_only': True})
+    assert det.generate_detections_one_batch([], []) == []
+    img = np.zeros((32, 48, 3), np.uint8)
+    with pytest.raises(ValueError, match='must be a list'):
+        det.generate_detections_one_batch(img, ['a'])
+    with pytest.raises(ValueError, match='image_id must be a list'):
+        det.generate_detections_one_batch([img], None)
+    with pytest.raises(ValueError, match='Length mismatch'):
+        det.generate_detections_one_batch([img, img], ['a'])
+    info = det.preprocess_image(img, 'a')
+    with pytest.raises(ValueError, match='Mixed input types'):
+        det.generate_detections_one_batch([info, img], None)
+    with pytest.raises(ValueError, match='Mixed input types'):
+        det.generate_detections_one_batch([img, info], ['a', 'b'])
+    with pytest.raises(RuntimeError, match='preprocess_only'):
+        det.generate_detections_one_batch([img], ['a'])

@@ -745,3 +745,22 @@ def test_modern_mode_through_the_detector():
             assert res[mode]['detections'] == want and res[mode]['max_detection_conf'] == want_max
         det._ctx.close()
     assert res['classic']['detections'] != res['modern']['detections']
+
+
+def test_threshold_one_gives_empty_detection_lists_and_ragged_batches():
+    """nothing above the threshold is an empty list with max_detection_conf 0.0 (not a failure); a batch larger than
+    the context's batch size and of three different shapes is split and regrouped transparently"""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.detector import HIPDetector
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5N6_TEST, seed=1)
+    det = HIPDetector(W, {'batch_size': 2, 'max_image_size': 320})
+    det.default_image_size = 320
+    imgs = (PU.structured_images(3, 240, 320, seed=1) + PU.structured_images(2, 320, 200, seed=2) +
+            PU.structured_images(2, 100, 100, seed=3))
+    ids = ['i%d.jpg' % i for i in range(len(imgs))]
+    res = det.generate_detections_one_batch(imgs, ids, detection_threshold=1.0)
+    assert [r['file'] for r in res] == ids
+    assert all(r['detections'] == [] and r['max_detection_conf'] == 0.0 and 'failure' not in r for r in res)
+    full = det.generate_detections_one_batch(imgs, ids, detection_threshold=1e-5)
+    one_by_one = [det.generate_detections_one_image(im, i, detection_threshold=1e-5) for im, i in zip(imgs, ids)]
+    assert full == one_by_one and any(r['detections'] for r in full)
