@@ -378,8 +378,16 @@ def _run_detector_with_shared_ring(image_files, detector, confidence_threshold, 
     bs = max(1, batch_size)
     n_workers = max(1, min(loader_workers, len(image_files)))
     n_slots = ring_slots_per_batch_image * bs + n_workers
-    loader = feed.ProcessLoader(image_files, n_workers, n_slots, ring_slot_bytes,
-                                want_meta=include_image_size or include_image_timestamp)
+    try:
+        loader = feed.ProcessLoader(image_files, n_workers, n_slots, ring_slot_bytes,
+                                    want_meta=include_image_size or include_image_timestamp)
+    except (OSError, MemoryError) as e:
+        # e.g. a container whose /dev/shm is smaller than the ring: the thread queue needs no shared memory
+        print('Warning: cannot create the shared-memory ring ({} slots of {} MB: {}); using loader threads'.format(
+            n_slots, ring_slot_bytes >> 20, str(e)))
+        return _run_detector_with_image_queue(image_files, detector, confidence_threshold, quiet, image_size,
+                                              include_image_size, include_image_timestamp, augment, loader_workers,
+                                              False, batch_size, on_results)
     ring = loader.ring
     try:
         if hasattr(detector, 'start_batch'):

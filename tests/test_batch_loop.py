@@ -115,6 +115,18 @@ def test_shared_memory_ring_loader_processes(image_dir, monkeypatch):
     assert _strip(got) == _strip(plain)
 
 
+def test_shared_ring_falls_back_to_threads_when_shared_memory_is_unavailable(image_dir, monkeypatch):
+    root, names = image_dir
+    plain = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True)
+
+    def no_shm(*a, **k):
+        raise OSError(28, 'No space left on device')
+    monkeypatch.setattr(RDB.feed, 'ProcessLoader', no_shm)
+    got = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True, batch_size=4,
+                                          use_image_queue=True, use_threads_for_queue=False, loader_workers=2)
+    assert _strip(got) == _strip(plain)
+
+
 class PipelinedStub(StubDetector):
     """StubDetector with the start_batch / finish_batch interface of HIPDetector: results must not depend
     on which interface the driver uses, and at most two tickets may be outstanding."""
