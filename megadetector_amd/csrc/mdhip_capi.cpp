@@ -65,6 +65,9 @@ struct Op {
     size_t f32_off = 0;       // decode: logits buffer offset ; conv with out_f32: same
     int f32_ld = 0;
     int forced_cfg = -1;
+    // the configuration chosen for the last (n, h, w): the table walk is not repeated on every launch
+    int memo_n = 0, memo_h = 0, memo_w = 0, memo_cfg = -1;
+    bool memo_from_table = false;
     int last_cfg = -1;
     // stats for the last (n,h,w)
     int gm = 0, gn = 0, gk = 0;
@@ -624,7 +627,11 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             fill_conv_args(ctx, op, n, h, w, a);
             int cfg = op.forced_cfg;
             bool from_table = false;
-            if (cfg < 0) {
+            const bool memo_hit = cfg < 0 && op.memo_cfg >= 0 && op.memo_n == n && op.memo_h == h && op.memo_w == w;
+            if (memo_hit) {
+                cfg = op.memo_cfg;
+                from_table = op.memo_from_table;
+            } else if (cfg < 0) {
                 const PackedConv& pc = ctx->packed[op.pc];
                 // 1. The canonical entry: same layer geometry (N, K, taps, stride, residual), per-image M equal
                 //    or nearest within 4x (the same layer at another image shape, e.g. 960x1280 instead of
@@ -681,9 +688,13 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             if (le == hipErrorInvalidValue && from_table) {      // table entry from another build: not applicable
                 (void)hipGetLastError();
                 cfg = choose_cfg(a.M, a.n_rows);
+                from_table = false;
                 le = conv_api(ctx).launch(cfg, a, s);
             }
             op.last_cfg = cfg;
+            if (op.forced_cfg < 0 && le == hipSuccess) {
+                op.memo_n = n; op.memo_h = h; op.memo_w = w; op.memo_cfg = cfg; op.memo_from_table = from_table;
+            }
             HIP_TRY(ctx, le);
             break;
         }
@@ -1279,6 +1290,7 @@ int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n) {
         if (entries[i].cfg < 0 || entries[i].cfg >= conv_num_cfgs())
             return fail(ctx, MDHIP_EINVAL, "tuned entry %d: cfg %d outside [0,%d)", i, entries[i].cfg, conv_num_cfgs());
     ctx->tuned.assign(entries, entries + n);
+    for (Op& op : ctx->ops) op.memo_cfg = -1;
     return MDHIP_OK;
 }
 
