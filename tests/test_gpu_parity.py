@@ -764,3 +764,29 @@ def test_threshold_one_gives_empty_detection_lists_and_ragged_batches():
     full = det.generate_detections_one_batch(imgs, ids, detection_threshold=1e-5)
     one_by_one = [det.generate_detections_one_image(im, i, detection_threshold=1e-5) for im, i in zip(imgs, ids)]
     assert full == one_by_one and any(r['detections'] for r in full)
+
+
+def test_full_size_configuration_batch_invariance():
+    """BASELINE.json configs[1] at full size -- MDv5 topology, batch 32, 1280x1280, the shipped tile table: every
+    value finite, and images 0 / 17 / 31 of the batch bit-identical to their single-image forward (a size-
+    independent property that catches 32-bit offset overflows and tile-edge bugs the small tests cannot)."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    B, S = 32, 1280
+    ctx = HipContext(W, device=0, max_batch=B, max_h=S, max_w=S)
+    try:
+        g = torch.Generator(device='cuda')
+        g.manual_seed(1)
+        x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda', generator=g)
+        ptrs = [int(x[i].data_ptr()) for i in range(B)]
+        ctx.preprocess(ptrs, [(S, S, S, S, 0, 0)] * B, S, S)
+        ctx.forward(B, S, S)
+        full = ctx.read_predictions(B)
+        assert full.shape == (B, 102000, 8) and np.isfinite(full).all()
+        for i in (0, 17, 31):
+            ctx.preprocess([ptrs[i]], [(S, S, S, S, 0, 0)], S, S)
+            ctx.forward(1, S, S)
+            np.testing.assert_array_equal(ctx.read_predictions(1)[0], full[i])
+    finally:
+        ctx.close()
