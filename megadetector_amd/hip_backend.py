@@ -82,7 +82,12 @@ class HipContext:
         entries.  Shapes without an entry use the built-in heuristic, so a missing or stale file only
         costs speed.
         """
-        path = path or self.TUNED_PATH
+        if path is None:
+            # a table measured for this storage type, if there is one (tuned_cfgs_fp16.json), else the bf16 table
+            path = self.TUNED_PATH
+            alt = self.TUNED_PATH.replace('.json', '_{}.json'.format(getattr(self, 'dtype', 'bf16')))
+            if getattr(self, 'dtype', 'bf16') != 'bf16' and os.path.exists(alt):
+                path = alt
         if not os.path.exists(path):
             return 0
         try:

@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'tuned_cfgs.json'))
     ap.add_argument('--table', default=None)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'])
     ap.add_argument('--family-from', default=None,
                     help='existing table (measured at the canonical batch size): only configurations of the same kernel '
                          'family (same fp32 summation order) as its entry for the layer are tried, so that an '
@@ -40,7 +41,7 @@ def main():
     from megadetector_amd.hip_backend import HipContext
     B, S = args.batch, args.size
     W = weights_io.synthetic_weights(getattr(yolo_yaml, args.model), seed=0)
-    ctx = HipContext(W, device=0, max_batch=B, max_h=S, max_w=S)
+    ctx = HipContext(W, device=0, dtype=args.dtype, max_batch=B, max_h=S, max_w=S)
     ctx.load_tuned('/nonexistent')      # measure against the heuristic, not an older table
     ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
     x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda')
