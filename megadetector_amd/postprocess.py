@@ -125,7 +125,11 @@ def format_detections(det, batch_hw, img_original_shape, scaling_shape, detectio
         bad = cls[order][(cls[order] < 1) | (cls[order] > 3)]
         if bad.size:
             raise KeyError('{} is not a valid class.'.format(int(bad[0])))
-    detections = [{'category': str(int(cls[i])), 'conf': float(conf[i]),
-                   'bbox': [float(v) for v in api[i]]} for i in order]
-    max_conf = float(max(0.0, conf[order].max()))
+    # bulk conversion to Python objects (one .tolist() per array) instead of per-element float()/str()
+    cats = [str(c) for c in cls[order].tolist()]
+    confs = conf[order].tolist()
+    boxes = api[order].tolist()
+    detections = [{'category': c, 'conf': f, 'bbox': b} for c, f, b in zip(cats, confs, boxes)]
+    max_conf = float(max(0.0, max(confs)))
     return detections, max_conf
+
