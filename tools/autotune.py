@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--model', default='YOLOV5X6_MD')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=1280)
+    ap.add_argument('--hw', default=None, help='HxW of the letterboxed input when it is not square (e.g. 960x1280)')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'tuned_cfgs.json'))
@@ -40,13 +41,15 @@ def main():
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.hip_backend import HipContext
     B, S = args.batch, args.size
+    HH, WW = (int(v) for v in args.hw.lower().split('x')) if args.hw else (S, S)
+    S = max(HH, WW)
     W = weights_io.synthetic_weights(getattr(yolo_yaml, args.model), seed=0)
     ctx = HipContext(W, device=0, dtype=args.dtype, max_batch=B, max_h=S, max_w=S)
     ctx.load_tuned('/nonexistent')      # measure against the heuristic, not an older table
     ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
-    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda')
-    ctx.preprocess([int(x[i].data_ptr()) for i in range(B)], [(S, S, S, S, 0, 0)] * B, S, S)
-    ctx.forward(B, S, S)                       # real activations in every buffer
+    x = torch.randint(0, 256, (B, HH, WW, 3), dtype=torch.uint8, device='cuda')
+    ctx.preprocess([int(x[i].data_ptr()) for i in range(B)], [(HH, WW, HH, WW, 0, 0)] * B, HH, WW)
+    ctx.forward(B, HH, WW)                     # real activations in every buffer
     infos = ctx.op_infos()
     ncfg = ctx.num_conv_cfgs()
     lines = []
@@ -73,7 +76,7 @@ def main():
                     continue
                 try:
                     ctx.set_op_cfg(o['op'], cfg)
-                    ms.append(min(ctx.time_op(o['op'], B, S, S, iters=args.iters) for _ in range(args.reps)))
+                    ms.append(min(ctx.time_op(o['op'], B, HH, WW, iters=args.iters) for _ in range(args.reps)))
                 except Exception:
                     ms.append(float('inf'))
             ctx.set_op_cfg(o['op'], -1)
@@ -96,7 +99,7 @@ def main():
             if e.get('batch', 32) != B or (e['m'], e['n'], e['k'], e['ntaps'], e['stride'], e['has_res']) not in entries]
     data = {'n_cfgs': ncfg, 'entries': keep + list(entries.values())}
     json.dump(data, open(args.out, 'w'), indent=1, sort_keys=True)
-    table = args.table or (os.path.splitext(args.out)[0] + '_{}_{}_{}.txt'.format(args.model, B, S))
+    table = args.table or (os.path.splitext(args.out)[0] + '_{}_{}_{}x{}.txt'.format(args.model, B, HH, WW))
     with open(table, 'w') as f:
         f.write('TFLOP/s per configuration (columns = cfg 0..{})\n'.format(ncfg - 1))
         f.write('\n'.join(lines) + '\n')
