@@ -43,8 +43,9 @@ __global__ void __launch_bounds__(256) write_kernel(uint4* __restrict__ out, siz
 }
 
 // 16 independent accumulators per wave, `iters` rounds of 16 MFMAs each
-__global__ void __launch_bounds__(256) mfma_kernel(float* out, int iters) {
+__global__ void __launch_bounds__(256) mfma_kernel(float* out, int iters, unsigned long long* cyc = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     bf16x8 a = {(short)threadIdx.x, 1, 2, 3, 4, 5, 6, 7}, b = {7, 6, 5, 4, 3, 2, 1, (short)blockIdx.x};
     f32x4 acc[16];
 #pragma unroll
@@ -57,6 +58,7 @@ __global__ void __launch_bounds__(256) mfma_kernel(float* out, int iters) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678f) out[0] = s;
+    if (cyc && blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = __builtin_amdgcn_s_memtime() - t0;
 #endif
 }
 
@@ -107,9 +109,15 @@ int main() {
     const int iters = 20000;
     for (int waves_per_simd = 1; waves_per_simd <= 2; ++waves_per_simd) {
         const int blocks = prop.multiProcessorCount * waves_per_simd;      // 4 waves per block = one per SIMD
-        ms = time_ms([&] { hipLaunchKernelGGL(mfma_kernel, dim3(blocks), dim3(256), 0, 0, out, iters); }, 3);
+        unsigned long long* cyc;
+        CK(hipMalloc(&cyc, 8));
+        ms = time_ms([&] { hipLaunchKernelGGL(mfma_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, cyc); }, 3);
+        unsigned long long hc = 0;
+        CK(hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost));
         const double flops = (double)blocks * 4 * iters * 16 * (2.0 * 16 * 16 * 32);
-        printf("MFMA 16x16x32 bf16, %d wave(s)/SIMD: %7.1f TFLOP/s  (%.2f ms)\n", waves_per_simd, flops / ms / 1e9, ms);
+        printf("MFMA 16x16x32 bf16, %d wave(s)/SIMD: %7.1f TFLOP/s  (%.2f ms; %.0f s_memtime cycles per launch = %.2f GHz shader clock "
+               "during the loop, %.1f cycles per MFMA and SIMD)\n", waves_per_simd, flops / ms / 1e9, ms, (double)hc,
+               (double)hc / (ms * 1e6), (double)hc / ((double)iters * 16 * waves_per_simd));
     }
     return 0;
 }
