@@ -790,3 +790,37 @@ def test_full_size_configuration_batch_invariance():
             np.testing.assert_array_equal(ctx.read_predictions(1)[0], full[i])
     finally:
         ctx.close()
+
+
+def test_two_contexts_interleaved_and_recreated(n6):
+    """One context per (process, GPU) is the contract, but nothing in the library may be process-global: a second
+    context with other weights / storage type, used in alternation with the first and then destroyed, must not
+    change the first one's results; a context created afterwards reproduces them."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W, ctx = n6
+    imgs = PU.random_images(2, 192, 256, seed=8)
+    geoms = _identity_geoms(imgs)
+    ctx.preprocess(imgs, geoms, 192, 256)
+    ctx.forward(2, 192, 256)
+    base = ctx.read_predictions(2).copy()
+    W2 = weights_io.synthetic_weights(yolo_yaml.YOLOV5S6_TEST, seed=9)
+    other = HipContext(W2, device=0, dtype='fp16', max_batch=2, max_h=256, max_w=256)
+    other.preprocess(imgs, geoms, 192, 256)
+    other.forward(2, 192, 256)
+    o1 = other.read_predictions(2).copy()
+    ctx.forward(2, 192, 256)                      # the first context still holds its own input and plan
+    np.testing.assert_array_equal(ctx.read_predictions(2), base)
+    other.forward(2, 192, 256)
+    np.testing.assert_array_equal(other.read_predictions(2), o1)
+    other.close()
+    ctx.preprocess(imgs, geoms, 192, 256)
+    ctx.forward(2, 192, 256)
+    np.testing.assert_array_equal(ctx.read_predictions(2), base)
+    again = HipContext(W, device=0, max_batch=4, max_h=320, max_w=320)
+    try:
+        again.preprocess(imgs, geoms, 192, 256)
+        again.forward(2, 192, 256)
+        np.testing.assert_array_equal(again.read_predictions(2), base)
+    finally:
+        again.close()
