@@ -310,10 +310,10 @@ def main():
             'dtype': args.dtype,
             'data': 'synthetic',
             'config': {
-                'workload': 'MDv5a topology (YOLOv5x6, nc=3, 163 convs, {3:.2f} GFLOP/image) ' + args.dtype + ', '
-                            '{0}x{4} letterbox, batch {1} per GPU, uint8 RGB inputs resident in HBM, seeded '
-                            'synthetic weights (no checkpoint available offline), NMS threshold {2}'.format(
-                                Hn, B, args.threshold, GFLOP_PER_IMAGE_1280 * Hn * Wn / (1280.0 * 1280.0), Wn),
+                'workload': ('MDv5a topology (YOLOv5x6, nc=3, 163 convs, {3:.2f} GFLOP/image) {5}, '
+                             '{0}x{4} letterbox, batch {1} per GPU, uint8 RGB inputs resident in HBM, seeded '
+                             'synthetic weights (no checkpoint available offline), NMS threshold {2}').format(
+                                 Hn, B, args.threshold, GFLOP_PER_IMAGE_1280 * Hn * Wn / (1280.0 * 1280.0), Wn, args.dtype),
                 'model': args.model, 'batch_per_gpu': B, 'image_size': S,
                 'parallelism': 'image queue sharded over {} GPU(s), one process per GPU, no collectives'.format(world),
             },
