@@ -190,6 +190,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run(2)                      # initialisation (first-touch of every buffer and code path), not a warm-up step
     run(args.warmup)
     # live roofline measurement: a HIP event pair on the launch stream around the conv stack of every
     # timed step (mdhip_forward = the 152 implicit-GEMM launches + 11 small pool/upsample/decode kernels)
