@@ -276,3 +276,35 @@ def test_two_rank_gloo_run_matches_single_process(image_dir, tmp_path):
     plain = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True, batch_size=3)
     assert _strip(got['merged']) == _strip(plain)
     assert got['slowest'] == 2.0
+
+
+def test_load_image_modes_and_exif_rotation(tmp_path):
+    """reference visualization_utils.py:103-175: RGBA / L are converted to RGB, EXIF orientations 3 / 6 / 8 are
+    applied (180 / 270 / 90 degrees, expand), mirrored orientations are left alone (the reference asserts and
+    swallows), unsupported modes raise"""
+    from PIL import Image
+    from megadetector_amd import feed
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (30, 50, 3), dtype=np.uint8)
+    Image.fromarray(base).save(tmp_path / 'rgb.png')
+    Image.fromarray(np.dstack([base, np.full((30, 50), 200, np.uint8)]), 'RGBA').save(tmp_path / 'rgba.png')
+    Image.fromarray(base[..., 0], 'L').save(tmp_path / 'gray.png')
+    for name in ('rgb.png', 'rgba.png', 'gray.png'):
+        im = feed.load_image(str(tmp_path / name))
+        a = np.asarray(im)
+        assert im.mode == 'RGB' and a.shape == (30, 50, 3) and a.dtype == np.uint8
+    np.testing.assert_array_equal(np.asarray(feed.load_image(str(tmp_path / 'rgb.png'))), base)
+    for orientation, shape in ((3, (30, 50)), (6, (50, 30)), (8, (50, 30)), (2, (30, 50))):
+        ex = Image.Exif()
+        ex[274] = orientation
+        p = tmp_path / 'o{}.jpg'.format(orientation)
+        Image.fromarray(base).save(p, exif=ex, quality=95)
+        im = feed.load_image(str(p))
+        assert np.asarray(im).shape[:2] == shape, orientation
+        plain = feed.load_image(str(p), ignore_exif_rotation=True)
+        assert np.asarray(plain).shape[:2] == (30, 50)
+    Image.fromarray(base).convert('CMYK').save(tmp_path / 'cmyk.jpg')
+    with pytest.raises(AttributeError, match='unsupported mode'):
+        feed.load_image(str(tmp_path / 'cmyk.jpg'))
+    meta = feed.image_metadata(feed.load_image(str(tmp_path / 'rgb.png')))
+    assert meta['width'] == 50 and meta['height'] == 30 and meta['datetime'] is None
