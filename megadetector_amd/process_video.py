@@ -271,6 +271,9 @@ def process_videos(model_file, input_video_file, output_json_file=None, frame_sa
         if batch_size > 1:
             opts['batch_size'] = batch_size
         detector = run_detector.load_detector(model_file, detector_options=opts)
+    import gc
+    gc.collect()
+    gc.freeze()              # see run_detector_batch.load_and_run_detector_batch
     if os.path.isfile(input_video_file):
         folder = os.path.dirname(input_video_file)
         videos = [(os.path.basename(input_video_file), input_video_file)]
