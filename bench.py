@@ -133,6 +133,11 @@ def main():
     # with every other blocking stream and measured ~1.5 ms per step slower)
     comp_s = torch.cuda.Stream()
     compute_stream = comp_s.cuda_stream
+    # NMS + D2H of step i run on their own stream, next to the forward of step i+1 (the library alternates between
+    # two prediction buffers); ordered with events
+    nms_s = torch.cuda.Stream()
+    fwd_done = [torch.cuda.Event() for _ in range(4)]
+    nms_done = [None] * 4
     if args.host_fed:
         # PCIe-inclusive variant: the batches live in pinned host memory; every step copies its batch
         # into one of two device buffers on a copy stream while the previous step computes
@@ -148,6 +153,18 @@ def main():
     # Software pipeline: the GPU work of step i (preprocess -> forward -> NMS -> D2H into a pinned
     # slot) is enqueued asynchronously, then the host formats the detections of step i-1 while the
     # GPU runs step i.  Every step's results are fully formatted inside the timed region.
+    def forward_and_nms(i):
+        k = i % 4
+        if nms_done[(i - 2) % 4] is not None:
+            comp_s.wait_event(nms_done[(i - 2) % 4])      # the prediction buffer this forward overwrites has been consumed
+        ctx.forward(B, Hn, Wn, stream=compute_stream)
+        fwd_done[k].record(comp_s)
+        nms_s.wait_event(fwd_done[k])
+        ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=k, stream=nms_s.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(nms_s)
+        nms_done[k] = ev
+
     def enqueue(i):
         if args.host_fed:
             k = i % 2
@@ -159,12 +176,10 @@ def main():
             comp_s.wait_event(copied[k])
             ctx.preprocess(dev_ptrs[k], geoms, Hn, Wn, stream=compute_stream)
             consumed[k].record(comp_s)
-            ctx.forward(B, Hn, Wn, stream=compute_stream)
-            ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=i % 4, stream=compute_stream)
+            forward_and_nms(i)
             return
         ctx.preprocess(ptr_lists[i % n_batches], geoms, Hn, Wn, stream=compute_stream)
-        ctx.forward(B, Hn, Wn, stream=compute_stream)
-        ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=i % 4, stream=compute_stream)
+        forward_and_nms(i)
 
     def collect(i):
         det, counts = ctx.nms_wait(slot=i % 4)

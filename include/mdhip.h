@@ -137,7 +137,10 @@ int mdhip_nms(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_
  * are enqueued on the stream and the call returns; results land in pinned host slot `slot`
  * (0 <= slot < MDHIP_NMS_SLOTS) owned by the context.  mdhip_nms_wait blocks until that slot is
  * complete and returns pointers into it ([n][max_det][6] floats, [n] counts), valid until the
- * slot is enqueued again. */
+ * slot is enqueued again. 
+ * Every forward writes the other of two prediction buffers, so mdhip_nms_enqueue may run on another stream
+ * than the forward of the next batch (order it behind its own forward with an event); it must have completed
+ * before the forward after next starts. */
 #define MDHIP_NMS_SLOTS 4
 int mdhip_nms_enqueue(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_det,
                       int slot, void* hip_stream);

@@ -98,7 +98,11 @@ struct mdhip_ctx {
     char* warena = nullptr;       // packed weights + biases + zero page + anchors
     size_t warena_bytes = 0;
     size_t zero_off = 0, anchors_off = 0;
-    size_t pred_off = 0;          // fp32 predictions [max_batch][A_max][no]
+    // fp32 predictions [max_batch][a_cap][no], two of them: every forward writes the other one, so that the NMS of
+    // batch i (on its own stream) may still read its predictions while the forward of batch i+1 runs
+    size_t pred_offs[2] = {0, 0};
+    int pred_cur = 0;
+    size_t pred_off = 0;          // = pred_offs[pred_cur]: the prediction of the last forward
     int a_max = 0;
     NmsScratch nms_scr{};
     size_t nms_out_off = 0, nms_cnt_off = 0;
@@ -815,7 +819,9 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     ctx->a_max = has_detect ? num_anchors_for(ctx, ctx->max_h, ctx->max_w) : 1;
     // room for the concatenated predictions of test-time augmentation (three passes, <= 3 x a_max)
     ctx->a_cap = has_detect ? 3 * ctx->a_max : 1;
-    ctx->pred_off = P.alloc_bytes((size_t)max_batch * ctx->a_cap * ctx->no * 4);
+    ctx->pred_offs[0] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * ctx->no * 4);
+    ctx->pred_offs[1] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * ctx->no * 4);
+    ctx->pred_off = ctx->pred_offs[0];
     size_t nms_kv[4];
     for (int i = 0; i < 4; ++i) nms_kv[i] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * 4);
     ctx->nms_out_off = P.alloc_bytes((size_t)max_batch * kNmsMaxDet * 6 * 4);
@@ -976,6 +982,8 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     if (ctx->time_forward) HIP_TRY(ctx, hipEventRecord(ctx->fwd_ev[slot][0], s));
     ctx->cur_tta = DecodeTta();
     ctx->cur_A = num_anchors_for(ctx, h, w);
+    ctx->pred_cur ^= 1;
+    ctx->pred_off = ctx->pred_offs[ctx->pred_cur];
     for (Op& op : ctx->ops)
         if (int rc = run_op(ctx, op, n, h, w, s)) return rc;
     if (ctx->time_forward) {
@@ -1024,6 +1032,8 @@ int mdhip_forward_tta(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     HIP_TRY(ctx, hipMemcpyAsync(orig, in, in_bytes, hipMemcpyDeviceToDevice, s));
     const int f16 = ctx->dtype == MDHIP_DTYPE_FP16;
     ctx->cur_A = total;
+    ctx->pred_cur ^= 1;
+    ctx->pred_off = ctx->pred_offs[ctx->pred_cur];
     int out_off = 0;
     for (int k = 0; k < 3; ++k) {
         if (k) HIP_TRY(ctx, launch_tta_scale(orig, in, n, h, w, sh[k], sw[k], oh[k], ow[k], flips[k], f16, s));

@@ -295,6 +295,7 @@ class HIPDetector:
             dev = torch.device('cuda', _device_ordinal(self.device))
             with torch.cuda.device(dev):
                 self._pl = {'torch': torch, 'dev': dev, 'copy_s': torch.cuda.Stream(), 'comp_s': torch.cuda.Stream(),
+                            'nms_s': torch.cuda.Stream(), 'nms_done': [None] * 4,
                             'stage': [None, None], 'copied': [torch.cuda.Event(), torch.cuda.Event()],
                             'consumed': [None, None], 'count': 0}
         return self._pl
@@ -339,8 +340,19 @@ class HIPDetector:
             ev = torch.cuda.Event()
             ev.record(comp)
             pl['consumed'][k] = ev
+            # NMS + D2H on their own stream, next to the following batch's forward (two prediction buffers in the
+            # library): behind this forward, and this forward behind the NMS that read the buffer it overwrites
+            prev = pl['nms_done'][(nms_slot - 2) % 4]
+            if prev is not None:
+                comp.wait_event(prev)
             ctx.forward(n, h, w, stream=comp.cuda_stream)
-            ctx.nms_enqueue(n, detection_threshold, self._nms_iou(), 300, slot=nms_slot, stream=comp.cuda_stream)
+            fwd_ev = torch.cuda.Event()
+            fwd_ev.record(comp)
+            pl['nms_s'].wait_event(fwd_ev)
+            ctx.nms_enqueue(n, detection_threshold, self._nms_iou(), 300, slot=nms_slot, stream=pl['nms_s'].cuda_stream)
+            done = torch.cuda.Event()
+            done.record(pl['nms_s'])
+            pl['nms_done'][nms_slot] = done
         return {'items': group_items, 'h': h, 'w': w, 'slot': nms_slot, 'copied': pl['copied'][k], 'images': images}
 
     def _collect_group(self, handle, results, detection_threshold):
