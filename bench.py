@@ -96,13 +96,21 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)')
+    # test hook: MDHIP_BENCH_ONE_GPU=1 runs every rank on device 0 with the gloo backend, so that the multi-rank code
+    # path can be exercised on a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    one_gpu = os.environ.get('MDHIP_BENCH_ONE_GPU', '0') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if one_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
 
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.hip_backend import HipContext
@@ -224,7 +232,7 @@ def main():
     fwd_ms_live = ctx.forward_times(min(args.steps, 64))
     ctx.time_forwards(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if one_gpu else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
