@@ -440,31 +440,66 @@ static const ConvCfg g_cfgs[] = {
 #undef X
 };
 
-// configuration ids: [0, kNumV1) = this file's kernel, then conv_v2.cpp's, then conv_v3.cpp's
+// configuration ids: [0, kNumV1) = this file's kernel, then the other families in the order of g_fams
 constexpr int kNumV1 = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
 int conv_num_v1_cfgs() { return kNumV1; }
-int conv_num_cfgs() { return kNumV1 + conv2_num_cfgs() + conv3_num_cfgs() + conv4_num_cfgs() + conv5_num_cfgs(); }
+
+namespace {
+bool conv2_supports_l(int, const ConvArgs& a) { return conv2_supports(a); }
+// one row per kernel family after the first: local configuration ids [0, num()), developer variants
+// (tools/convbench.cpp) behind them at the negative ids  dev_base - k
+struct Family {
+    int (*num)();
+    const ConvCfg& (*cfg)(int);
+    bool (*supports)(int, const ConvArgs&);
+    hipError_t (*launch)(int, const ConvArgs&, hipStream_t);
+    hipError_t (*init)();
+    bool bitwise;        // false: equals the implicit-GEMM kernels up to fp32 summation order only (other K order)
+    int dev_base;        // developer variant k (0, 1, ...) is addressed as  dev_base - k
+};
+const Family g_fams[] = {
+    {conv2_num_cfgs, conv2_cfg, conv2_supports_l, conv2_launch, conv2_init, true, -1},
+    {conv4_num_cfgs, conv4_cfg, conv4_supports, conv4_launch, conv4_init, false, -201},
+    {conv5_num_cfgs, conv5_cfg, conv5_supports, conv5_launch, conv5_init, false, -301},
+    {conv6_num_cfgs, conv6_cfg, conv6_supports, conv6_launch, conv6_init, false, -401},
+};
+constexpr int kNumFams = (int)(sizeof(g_fams) / sizeof(g_fams[0]));
+// family and local id of a global id >= kNumV1
+const Family* find_family(int cfg, int* local) {
+    int i = cfg - kNumV1;
+    for (int f = 0; f < kNumFams; ++f) {
+        const int n = g_fams[f].num();
+        if (i < n) { *local = i; return &g_fams[f]; }
+        i -= n;
+    }
+    return nullptr;
+}
+}  // namespace
+
+int conv_num_cfgs() {
+    int n = kNumV1;
+    for (int f = 0; f < kNumFams; ++f) n += g_fams[f].num();
+    return n;
+}
 const ConvCfg& conv_cfg(int i) {
     if (i < kNumV1) return g_cfgs[i];
-    i -= kNumV1;
-    if (i < conv2_num_cfgs()) return conv2_cfg(i);
-    i -= conv2_num_cfgs();
-    if (i < conv3_num_cfgs()) return conv3_cfg(i);
-    i -= conv3_num_cfgs();
-    if (i < conv4_num_cfgs()) return conv4_cfg(i);
-    return conv5_cfg(i - conv4_num_cfgs());
+    int l = 0;
+    const Family* f = find_family(i, &l);
+    return f ? f->cfg(l) : g_cfgs[0];
 }
-// conv_v4.cpp's and conv_v5.cpp's results agree with the implicit-GEMM kernels to rounding only (different K order)
-bool conv_cfg_is_bitwise_family(int cfg) { return cfg < kNumV1 + conv2_num_cfgs() + conv3_num_cfgs(); }
+bool conv_cfg_is_bitwise_family(int cfg) {
+    if (cfg < kNumV1) return true;
+    int l = 0;
+    const Family* f = find_family(cfg, &l);
+    return f ? f->bitwise : true;
+}
 
 bool conv_supports(int cfg, const ConvArgs& a) {
     if (cfg < 0 || cfg >= conv_num_cfgs()) return false;
     if (cfg < kNumV1) return true;                                  // the first-generation kernel takes every op
-    if (cfg < kNumV1 + conv2_num_cfgs()) return conv2_supports(a);
-    if (cfg < kNumV1 + conv2_num_cfgs() + conv3_num_cfgs()) return conv3_supports(a);
-    const int c4 = cfg - kNumV1 - conv2_num_cfgs() - conv3_num_cfgs();
-    if (c4 < conv4_num_cfgs()) return conv4_supports(c4, a);
-    return conv5_supports(c4 - conv4_num_cfgs(), a);
+    int l = 0;
+    const Family* f = find_family(cfg, &l);
+    return f && f->supports(l, a);
 }
 
 hipError_t conv_init() {
@@ -475,27 +510,23 @@ hipError_t conv_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs[id].lds_bytes);
     MDHIP_CONV_CFGS(X)
 #undef X
-    if (e == hipSuccess) e = conv2_init();
-    if (e == hipSuccess) e = conv3_init();
-    if (e == hipSuccess) e = conv4_init();
-    if (e == hipSuccess) e = conv5_init();
+    for (int f = 0; f < kNumFams && e == hipSuccess; ++f) e = g_fams[f].init();
     return e;
 }
 
 hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
-    // negative ids address the developer variants (tools/convbench.cpp): -1, -2, ... conv_v2.cpp's,
-    // -101, -102, ... conv_v3.cpp's, -201, ... conv_v4.cpp's, -301, ... conv_v5.cpp's
+    // negative ids address the developer variants (tools/convbench.cpp): family f's k-th variant is dev_base - k
     if (cfg >= conv_num_cfgs()) return hipErrorInvalidValue;
-    if (cfg <= -301) return conv5_launch(conv5_num_cfgs() - 301 - cfg, a, s);
-    if (cfg <= -201) return conv4_launch(conv4_num_cfgs() - 201 - cfg, a, s);
-    if (cfg <= -101) return conv3_launch(conv3_num_cfgs() - 101 - cfg, a, s);
-    if (cfg < 0) return conv2_launch(conv2_num_cfgs() - 1 - cfg, a, s);
-    if (cfg >= kNumV1 + conv2_num_cfgs() + conv3_num_cfgs() + conv4_num_cfgs())
-        return conv5_launch(cfg - kNumV1 - conv2_num_cfgs() - conv3_num_cfgs() - conv4_num_cfgs(), a, s);
-    if (cfg >= kNumV1 + conv2_num_cfgs() + conv3_num_cfgs())
-        return conv4_launch(cfg - kNumV1 - conv2_num_cfgs() - conv3_num_cfgs(), a, s);
-    if (cfg >= kNumV1 + conv2_num_cfgs()) return conv3_launch(cfg - kNumV1 - conv2_num_cfgs(), a, s);
-    if (cfg >= kNumV1) return conv2_launch(cfg - kNumV1, a, s);
+    if (cfg < 0) {
+        for (int f = kNumFams - 1; f >= 0; --f)
+            if (cfg <= g_fams[f].dev_base) return g_fams[f].launch(g_fams[f].num() + (g_fams[f].dev_base - cfg), a, s);
+        return hipErrorInvalidValue;
+    }
+    if (cfg >= kNumV1) {
+        int l = 0;
+        const Family* f = find_family(cfg, &l);
+        return f ? f->launch(l, a, s) : hipErrorInvalidValue;
+    }
     const ConvCfg& c = g_cfgs[cfg];
     ConvArgs p = a;
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;

@@ -116,11 +116,11 @@ struct ConvCfg {
 
 // The conv API exists once per storage type (see MDHIP_ST above):
 //   conv_*  : dispatch over all kernels (conv_igemm.cpp); ids [0, conv_num_v1_cfgs()) run conv_igemm.cpp's
-//             kernel (every shape), then conv_v2.cpp's, conv_v3.cpp's, conv_v4.cpp's, conv_v5.cpp's
+//             kernel (every shape), then conv_v2.cpp's, conv_v4.cpp's, conv_v5.cpp's, conv_v6.cpp's
 //   conv2_* : second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
-//   conv3_* : 32-deep slabs, 4-stage ring, counted waits (conv_v3.cpp)
 //   conv4_* : row-patch direct convolution for 3x3 / stride 1 (conv_v4.cpp)
 //   conv5_* : 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp)
+//   conv6_* : the same reuse with 32x32x16 MFMA fragments and one 8-wave workgroup per CU (conv_v6.cpp)
 // conv_launch returns hipSuccess or the launch error; conv_init raises the dynamic-LDS limits (one-off);
 // conv_cfg_is_bitwise_family is false for kernels whose result equals the others' up to fp32 summation
 // order only.
@@ -137,11 +137,6 @@ struct ConvCfg {
     bool conv2_supports(const ConvArgs& a); \
     hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s); \
     hipError_t conv2_init(); \
-    int conv3_num_cfgs(); \
-    const ConvCfg& conv3_cfg(int i); \
-    bool conv3_supports(const ConvArgs& a); \
-    hipError_t conv3_launch(int cfg, const ConvArgs& a, hipStream_t s); \
-    hipError_t conv3_init(); \
     int conv4_num_cfgs(); \
     const ConvCfg& conv4_cfg(int i); \
     bool conv4_supports(int cfg, const ConvArgs& a); \
@@ -151,7 +146,12 @@ struct ConvCfg {
     const ConvCfg& conv5_cfg(int i); \
     bool conv5_supports(int cfg, const ConvArgs& a); \
     hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s); \
-    hipError_t conv5_init();
+    hipError_t conv5_init(); \
+    int conv6_num_cfgs(); \
+    const ConvCfg& conv6_cfg(int i); \
+    bool conv6_supports(int cfg, const ConvArgs& a); \
+    hipError_t conv6_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv6_init();
 namespace st_bf16 {
 MDHIP_CONV_API
 }

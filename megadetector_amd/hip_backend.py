@@ -95,7 +95,18 @@ class HipContext:
         except Exception:
             return 0
         ncfg = self.lib.mdhip_num_conv_cfgs()
-        entries = [e for e in entries if 0 <= int(e['cfg']) < ncfg]
+        # an entry names its configuration; the id is looked up in THIS build (ids shift when a kernel family is
+        # added or removed), entries without a name keep their id, entries naming an unknown configuration are dropped
+        by_name = {self.lib.mdhip_conv_cfg_name(i).decode(): i for i in range(ncfg)}
+        resolved = []
+        for e in entries:
+            if e.get('name'):
+                if e['name'] not in by_name:
+                    continue
+                e = dict(e, cfg=by_name[e['name']])
+            if 0 <= int(e['cfg']) < ncfg:
+                resolved.append(e)
+        entries = resolved
         arr = (_lib.mdhip_tuned * max(1, len(entries)))()
         for i, e in enumerate(entries):
             arr[i].m, arr[i].n, arr[i].k = int(e['m']), int(e['n']), int(e['k'])

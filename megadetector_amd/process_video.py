@@ -270,6 +270,8 @@ def process_videos(model_file, input_video_file, output_json_file=None, frame_sa
         opts = dict(detector_options or {})
         if batch_size > 1:
             opts['batch_size'] = batch_size
+        if image_size is not None and int(image_size) > int(opts.get('max_image_size', 1280) or 1280):
+            opts['max_image_size'] = int(image_size)     # the device arena is planned at construction
         detector = run_detector.load_detector(model_file, detector_options=opts)
     import gc
     gc.collect()

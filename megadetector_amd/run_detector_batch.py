@@ -313,19 +313,32 @@ def _producer(q, file_q, preprocessor, image_size, producer_id):
     q.put(None)
 
 
+def _make_preprocessor(detector, detector_options):
+    """A weight-free, HIP-free twin of `detector` for the producer side: same options, same geometry attributes."""
+    from .detector import HIPDetector
+    opts = copy.deepcopy(dict(detector_options or {}))
+    if getattr(detector, 'compatibility_mode', None) is not None:
+        opts['compatibility_mode'] = detector.compatibility_mode
+    opts['preprocess_only'] = True
+    pre = HIPDetector('synthetic', opts)
+    for attr in ('default_image_size', 'letterbox_stride', 'compatibility_mode'):
+        if hasattr(detector, attr):
+            setattr(pre, attr, getattr(detector, attr))
+    return pre
+
+
 def _run_detector_with_image_queue(image_files, detector, confidence_threshold, quiet, image_size,
                                    include_image_size, include_image_timestamp, augment, loader_workers,
-                                   preprocess_on_image_queue, batch_size, on_results):
+                                   preprocess_on_image_queue, batch_size, on_results, detector_options=None):
     q = queue.Queue(max_queue_size)
     file_q = queue.Queue()
     for f in image_files:
         file_q.put(f)
     preprocessor = None
     if preprocess_on_image_queue:
-        from .detector import HIPDetector
-        preprocessor = HIPDetector('synthetic', {'preprocess_only': True})
-        preprocessor.default_image_size = detector.default_image_size
-        preprocessor.letterbox_stride = detector.letterbox_stride
+        # reference _producer_func (:143-152): load_detector(..., deepcopy(detector_options) + preprocess_only), so the
+        # producers letterbox in the consumer's compatibility mode
+        preprocessor = _make_preprocessor(detector, detector_options)
     n_workers = max(1, min(loader_workers, len(image_files)))
     threads = [threading.Thread(target=_producer, args=(q, file_q, preprocessor, image_size, i), daemon=True)
                for i in range(n_workers)]
@@ -484,6 +497,11 @@ def load_and_run_detector_batch(model_file, image_file_names, checkpoint_path=No
     batch_size = max(1, int(batch_size))
     if batch_size > 1:
         detector_options['batch_size'] = batch_size           # reference :1227-1228
+    if image_size is not None and int(image_size) > int(detector_options.get('max_image_size', 1280) or 1280):
+        # the device arena is planned at construction (default: the model's own size, 1280): a user-supplied size
+        # above it (the reference accepts any, :988-994) must be known there, or every image would come back as an
+        # inference failure
+        detector_options['max_image_size'] = int(image_size)
 
     if detector is None:
         t0 = time.time()
@@ -515,7 +533,8 @@ def load_and_run_detector_batch(model_file, image_file_names, checkpoint_path=No
     elif use_image_queue:
         _run_detector_with_image_queue(image_files, detector, confidence_threshold, quiet, image_size,
                                        include_image_size, include_image_timestamp, augment, loader_workers,
-                                       preprocess_on_image_queue, batch_size, on_results)
+                                       preprocess_on_image_queue, batch_size, on_results,
+                                       detector_options=detector_options)
     elif batch_size > 1:
         for batch in _group_into_batches(image_files, batch_size):
             on_results(_process_batch(batch, detector, confidence_threshold, quiet, image_size,
@@ -525,6 +544,11 @@ def load_and_run_detector_batch(model_file, image_file_names, checkpoint_path=No
             on_results([_process_image(im_file, detector, confidence_threshold, quiet=quiet, image_size=image_size,
                                        include_image_size=include_image_size,
                                        include_image_timestamp=include_image_timestamp, augment=augment)])
+    # a loader process that died mid-list, or a result dropped anywhere above, must not pass silently
+    have = set(r['file'] for r in results)
+    missing = [f for f in image_files if f not in have]
+    if missing:
+        raise RuntimeError('{} images have no result (first: {})'.format(len(missing), missing[0]))
     return results
 
 
@@ -593,46 +617,105 @@ def merge_shard_results(shard_results, expected_files=None):
     return merged
 
 
+def shard_checkpoint_path(checkpoint_path, gpu):
+    """every shard process writes its own checkpoint file: G processes must not rewrite one file"""
+    return None if checkpoint_path is None else '{}.shard{}'.format(checkpoint_path, gpu)
+
+
 def _shard_worker(gpu, model_file, files, kwargs, out_q):
     try:
         opts = dict(kwargs.pop('detector_options', None) or {})
         opts['device'] = 'cuda:{}'.format(gpu)
+        kwargs['checkpoint_path'] = shard_checkpoint_path(kwargs.get('checkpoint_path'), gpu)
         res = load_and_run_detector_batch(model_file, files, detector_options=opts, **kwargs)
         out_q.put((gpu, res, None))
     except Exception as e:        # the parent reports it; a dead shard must not hang the join
         out_q.put((gpu, None, repr(e)))
 
 
-def run_sharded(model_file, image_file_names, n_gpus, **kwargs):
+def run_sharded(model_file, image_file_names, n_gpus, results=None, worker=None, **kwargs):
     """
     Runs load_and_run_detector_batch on n_gpus GPUs of one node: the image list is split
     `i % n_gpus`, each shard runs in its own *spawned* process pinned to one GPU
     (detector_options['device'] = 'cuda:g', reference pytorch_detector.py:853-858), results are
     merged on the host.  There is no inter-GPU traffic.
+
+    Checkpoints: shard g writes `<checkpoint_path>.shard<g>` (shard_checkpoint_path).  `results` (restored from a
+    checkpoint, single-GPU or merged from shard files by load_sharded_checkpoints) are kept as they are; only the
+    files without a result are sharded, so a resumed run recomputes nothing.
+    `worker` replaces _shard_worker in the CPU tests.
     """
     import multiprocessing as mp
     files = _resolve_image_list(image_file_names)
+    results = list(results) if results else []
+    done = set(r['file'] for r in results)
+    todo = [f for f in files if f not in done]
     if n_gpus <= 1:
-        return load_and_run_detector_batch(model_file, files, **kwargs)
+        return load_and_run_detector_batch(model_file, files, results=results, **kwargs)
     ctx = mp.get_context('spawn')
     out_q = ctx.Queue()
-    shards = shard_image_list(files, n_gpus)
+    shards = shard_image_list(todo, n_gpus)
     procs = []
     for g in range(n_gpus):
-        p = ctx.Process(target=_shard_worker, args=(g, model_file, shards[g], dict(kwargs), out_q))
+        p = ctx.Process(target=worker or _shard_worker, args=(g, model_file, shards[g], dict(kwargs), out_q))
         p.start()
         procs.append(p)
     got = {}
-    for _ in range(n_gpus):
-        g, res, err = out_q.get()
-        if err is not None:
-            for p in procs:
+    try:
+        while len(got) < n_gpus:
+            try:
+                g, res, err = out_q.get(timeout=2.0)
+            except queue.Empty:
+                # a shard killed by a signal (HIP fault, OOM killer) never posts: notice its exit instead of waiting
+                dead = [g for g, p in enumerate(procs) if g not in got and not p.is_alive()]
+                if dead and out_q.empty():
+                    time.sleep(0.5)                  # its last message may still be in the pipe
+                    if out_q.empty():
+                        raise RuntimeError('shard {} exited with code {} without a result'.format(
+                            dead[0], procs[dead[0]].exitcode))
+                continue
+            if err is not None:
+                raise RuntimeError('shard {} failed: {}'.format(g, err))
+            got[g] = res
+    except BaseException:
+        for p in procs:
+            if p.is_alive():
                 p.terminate()
-            raise RuntimeError('shard {} failed: {}'.format(g, err))
-        got[g] = res
+        raise
     for p in procs:
         p.join()
-    return merge_shard_results([got[g] for g in range(n_gpus)], expected_files=files)
+    return merge_shard_results([results] + [got[g] for g in range(n_gpus)], expected_files=files)
+
+
+def load_sharded_checkpoints(checkpoint_path, n_gpus):
+    """what a sharded run left behind: the union of `<checkpoint_path>.shard<g>` (and of the plain file, if any)"""
+    results, seen = [], set()
+    paths = [checkpoint_path] + [shard_checkpoint_path(checkpoint_path, g) for g in range(max(1, n_gpus))]
+    for p in paths:
+        if p and os.path.isfile(p):
+            for r in load_checkpoint(p):
+                if r['file'] not in seen:
+                    seen.add(r['file'])
+                    results.append(r)
+    return results
+
+
+def load_previous_results(previous_results_file, image_folder):
+    """
+    reference :2056-2096: results of an earlier pass over the same folder (relative paths), made absolute the way
+    the final output stage expects them.  Returns the list of image entries.
+    """
+    assert os.path.isfile(previous_results_file), 'Could not find previous results file {}'.format(previous_results_file)
+    with open(previous_results_file, 'r') as f:
+        previous = json.load(f)
+    assert previous['detection_categories'] == DEFAULT_DETECTOR_LABEL_MAP, \
+        "Can't merge previous results when those results use a different set of detection categories"
+    print('Loaded previous results for {} images from {}'.format(len(previous['images']), previous_results_file))
+    assert os.path.isdir(image_folder)
+    for im in previous['images']:
+        assert not os.path.isabs(im['file']), 'When processing previous results, relative paths are required'
+        im['file'] = os.path.join(image_folder, im['file']).replace('\\', '/')
+    return previous['images']
 
 
 # --------------------------------------------------------------------------------------------
@@ -664,21 +747,49 @@ def main(argv=None):
     ap.add_argument('--include_image_size', action='store_true')
     ap.add_argument('--include_image_timestamp', action='store_true')
     ap.add_argument('--detector_options', nargs='*', metavar='KEY=VALUE', default='')
+    ap.add_argument('--previous_results_file', type=str, default=None,
+                    help='results of a previous run over the same folder: images in it are skipped and its entries '
+                         'are merged into the output (needs a folder and --output_relative_filenames; reference :1894)')
+    ap.add_argument('--overwrite_handling', type=str, default='overwrite', choices=['skip', 'overwrite', 'error'])
     ap.add_argument('--n_gpus', type=int, default=1, help='shard the image list over this many GPUs')
     ap.add_argument('--verbose', action='store_true')
     args = ap.parse_args(argv)
 
     assert 0.0 <= args.threshold <= 1.0, 'Confidence threshold needs to be between 0 and 1'
     assert args.output_file.endswith('.json'), 'output_file specified needs to end with .json'
+    if args.checkpoint_frequency != -1:
+        assert args.checkpoint_frequency > 0, 'Checkpoint_frequency needs to be > 0 or == -1'
+    if args.output_relative_filenames:
+        assert os.path.isdir(args.image_file), \
+            'Could not find folder {}, must supply a folder when --output_relative_filenames is set'.format(args.image_file)
+    if args.previous_results_file is not None:
+        assert os.path.isdir(args.image_file) and args.output_relative_filenames, \
+            'Can only process previous results when using relative paths'
+    if os.path.exists(args.output_file):
+        if args.overwrite_handling == 'overwrite':
+            print('Warning: output file {} already exists and will be overwritten'.format(args.output_file))
+        elif args.overwrite_handling == 'skip':
+            print('Output file {} exists, returning'.format(args.output_file))
+            return
+        else:
+            raise Exception('Output file {} exists'.format(args.output_file))
     results = None
     checkpoint_path = args.checkpoint_path
     if args.checkpoint_frequency > 0 and checkpoint_path is None:
         checkpoint_path = os.path.join(os.path.dirname(os.path.abspath(args.output_file)),
                                        'md_checkpoint_{}.json'.format(datetime.now().strftime('%Y%m%d%H%M%S')))
     if args.resume_from_checkpoint:
-        results = load_checkpoint(args.resume_from_checkpoint)
+        results = load_sharded_checkpoints(args.resume_from_checkpoint, args.n_gpus) if args.n_gpus > 1 \
+            else load_checkpoint(args.resume_from_checkpoint)
     files = _resolve_image_list(args.image_file)
     print('{} image files found in the input'.format(len(files)))
+    previous_images = None
+    if args.previous_results_file is not None:
+        previous_images = load_previous_results(args.previous_results_file, args.image_file)
+        previous_set = set(im['file'] for im in previous_images)
+        keep = [f for f in files if f.replace('\\', '/') not in previous_set]
+        print('Based on previous results file, processing {} of {} images'.format(len(keep), len(files)))
+        files = keep
     kwargs = dict(checkpoint_path=checkpoint_path, confidence_threshold=args.threshold,
                   checkpoint_frequency=args.checkpoint_frequency, use_image_queue=args.use_image_queue,
                   quiet=args.quiet, image_size=args.image_size, include_image_size=args.include_image_size,
@@ -688,18 +799,24 @@ def main(argv=None):
                   verbose_output=args.verbose, use_threads_for_queue=args.use_threads_for_queue)
     t0 = time.time()
     if args.n_gpus > 1:
-        results = run_sharded(args.detector_file, files, args.n_gpus, **kwargs)
+        results = run_sharded(args.detector_file, files, args.n_gpus, results=results, **kwargs)
     else:
         results = load_and_run_detector_batch(args.detector_file, files, results=results, **kwargs)
     elapsed = time.time() - t0
     print('Finished inference for {} images in {:.1f} s ({:.2f} images per second)'.format(
         len(results), elapsed, len(results) / max(elapsed, 1e-9)))
     base = os.path.abspath(args.image_file) if (args.output_relative_filenames and os.path.isdir(args.image_file)) else None
+    if previous_images is not None:                      # reference :2166-2171
+        previous_set = set(im['file'] for im in previous_images)
+        assert not previous_set.intersection(r['file'] for r in results), \
+            'Previous results handling error: redundant image filenames'
+        results.extend(previous_images)
     write_results_to_file(results, args.output_file, relative_path_base=base, detector_file=args.detector_file,
                           include_max_conf=args.include_max_conf)
-    if checkpoint_path and os.path.isfile(checkpoint_path):
-        os.remove(checkpoint_path)
-        print('Deleted checkpoint file {}'.format(checkpoint_path))
+    for cp in [checkpoint_path] + [shard_checkpoint_path(checkpoint_path, g) for g in range(max(1, args.n_gpus))]:
+        if cp and os.path.isfile(cp):
+            os.remove(cp)
+            print('Deleted checkpoint file {}'.format(cp))
 
 
 if __name__ == '__main__':

@@ -127,7 +127,25 @@ class _CheckpointUnpickler(pickle.Unpickler):
     the yolov5 package, so `models.yolo.DetectionModel`, `models.common.Conv` ... unpickle
     without that package (reference pytorch_detector.py:950-957 needs them importable).
     """
-    _SAFE_PREFIXES = ('torch', 'collections', 'numpy', '_codecs', 'pathlib')
+    # Exact (module, name) pairs, not namespaces: `torch.*` / `numpy.*` as a whole also hold callables a crafted file
+    # could REDUCE (torch.hub.load, torch.utils.cpp_extension.load_inline, numpy.load ...).  This narrows what a file
+    # can reach; it is NOT a sandbox -- load checkpoints you trust (the reference does torch.load(weights_only=False),
+    # pytorch_detector.py:929-948).
+    _SAFE_GLOBALS = {
+        ('collections', 'OrderedDict'), ('collections', 'defaultdict'),
+        ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_tensor'),
+        ('torch._utils', '_rebuild_parameter'), ('torch._utils', '_rebuild_parameter_with_state'),
+        ('torch._utils', '_rebuild_qtensor'),
+        ('torch._tensor', '_rebuild_from_type_v2'), ('torch', 'Tensor'), ('torch', 'Size'), ('torch', 'device'),
+        ('torch', 'dtype'), ('torch.nn.parameter', 'Parameter'), ('torch.serialization', '_get_layout'),
+        ('torch.storage', 'TypedStorage'), ('torch.storage', 'UntypedStorage'), ('torch.storage', '_load_from_bytes'),
+        ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+        ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+        ('numpy', 'ndarray'), ('numpy', 'dtype'), ('_codecs', 'encode'),
+        ('pathlib', 'PosixPath'), ('pathlib', 'WindowsPath'), ('pathlib', 'PurePosixPath'), ('pathlib', 'PureWindowsPath'),
+        ('pathlib', 'Path'),
+    }
+    _TORCH_STORAGE_OR_DTYPE = ('Storage',)          # torch.FloatStorage, torch.HalfStorage, ... (legacy typed storages)
     # plain data types only: `builtins` also holds eval / exec / getattr / __import__
     _SAFE_BUILTINS = ('set', 'frozenset', 'list', 'dict', 'tuple', 'slice', 'range', 'complex', 'int', 'float',
                       'bool', 'str', 'bytes', 'bytearray', 'object')
@@ -138,8 +156,18 @@ class _CheckpointUnpickler(pickle.Unpickler):
                 import builtins
                 return getattr(builtins, name)
             raise pickle.UnpicklingError('refusing to unpickle {}.{}'.format(module, name))
-        if module.split('.')[0] in self._SAFE_PREFIXES:
+        if (module, name) in self._SAFE_GLOBALS:
             return super().find_class(module, name)
+        if module == 'torch' and name.endswith(self._TORCH_STORAGE_OR_DTYPE) and '.' not in name:
+            return super().find_class(module, name)
+        if module.startswith('torch.nn.modules.') and '.' not in name:
+            # layer classes of torch.nn (Conv2d, BatchNorm2d, SiLU, Upsample, MaxPool2d, Sequential, ModuleList ...):
+            # only actual nn.Module subclasses, never a function of those modules
+            cls = super().find_class(module, name)
+            import torch
+            if isinstance(cls, type) and issubclass(cls, torch.nn.Module):
+                return cls
+            raise pickle.UnpicklingError('refusing to unpickle {}.{}'.format(module, name))
         if module.split('.')[0] in ('models', 'utils', 'yolov5', 'ultralytics', '__main__'):
             return _stub_class(module, name)
         raise pickle.UnpicklingError('refusing to unpickle {}.{}'.format(module, name))

@@ -189,12 +189,14 @@ def uninstall():
         sys.modules.pop(name, None)
 
 
-def build_model(yaml, seed=0):
+def build_model(yaml, seed=0, gain=1.75):
     """
     A DetectionModel with random conv weights AND non-trivial BatchNorm statistics, in eval mode.  Scales are
     chosen as in megadetector_amd.weights_io.synthetic_weights (zero-mean kernels, gain 1.75 per Conv, 0.6 on the
     residual branch) so that activations stay O(1..10) through the 33 layers -- a network whose activations
-    explode turns rounding differences into sign flips of the logits and tests nothing.
+    explode turns rounding differences into sign flips of the logits and tests nothing.  On the deep x6 topology
+    1.75 already amplifies a perturbation ~4x per head C3 (measured: 5e-6 at layer 11 -> 2e-2 at layer 32); pass a
+    smaller gain (1.3) for a network that is contractive like a trained one.
     """
     common, yolo = _install()
     torch.manual_seed(seed)
@@ -209,13 +211,13 @@ def build_model(yaml, seed=0):
             w = torch.randn(m.conv.weight.shape, generator=g)
             w -= w.mean(dim=(1, 2, 3), keepdim=True)
             fan = w.shape[1] * w.shape[2] * w.shape[3]
-            gain = 0.6 if id(m) in residual_cv2 else 1.75
+            g_conv = 0.6 if id(m) in residual_cv2 else gain
             nf = m.bn.num_features
             m.bn.weight.data = 0.8 + 0.4 * torch.rand(nf, generator=g)
             m.bn.bias.data = 0.1 * torch.randn(nf, generator=g)
             m.bn.running_mean.data = 0.1 * torch.randn(nf, generator=g)
             m.bn.running_var.data = 0.7 + 0.6 * torch.rand(nf, generator=g)
-            m.conv.weight.data = w * (gain / fan ** 0.5)
+            m.conv.weight.data = w * (g_conv / fan ** 0.5)
         elif isinstance(m, yolo.Detect):
             for conv in m.m:
                 fan = conv.weight.shape[1]

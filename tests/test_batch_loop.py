@@ -308,3 +308,139 @@ def test_load_image_modes_and_exif_rotation(tmp_path):
         feed.load_image(str(tmp_path / 'cmyk.jpg'))
     meta = feed.image_metadata(feed.load_image(str(tmp_path / 'rgb.png')))
     assert meta['width'] == 50 and meta['height'] == 30 and meta['datetime'] is None
+
+
+# --------------------------------------------------------------------------------------------
+# round 2: sharded checkpoints / resume / liveness, --previous_results_file, option forwarding
+# --------------------------------------------------------------------------------------------
+def _stub_shard_worker(gpu, model_file, files, kwargs, out_q):
+    """_shard_worker with the stub detector instead of a GPU (same checkpoint-path rule)"""
+    try:
+        kwargs = dict(kwargs)
+        kwargs.pop('detector_options', None)
+        kwargs['checkpoint_path'] = RDB.shard_checkpoint_path(kwargs.get('checkpoint_path'), gpu)
+        res = RDB.load_and_run_detector_batch(model_file, files, detector=StubDetector(), **kwargs)
+        out_q.put((gpu, res, None))
+    except Exception as e:
+        out_q.put((gpu, None, repr(e)))
+
+
+def _dying_shard_worker(gpu, model_file, files, kwargs, out_q):
+    if gpu == 1:
+        os._exit(3)                # what a HIP fault or the OOM killer looks like from the parent
+    _stub_shard_worker(gpu, model_file, files, kwargs, out_q)
+
+
+def test_sharded_run_writes_one_checkpoint_per_shard_and_resumes(image_dir, tmp_path):
+    root, names = image_dir
+    ck = str(tmp_path / 'ck.json')
+    plain = RDB.load_and_run_detector_batch('stub', names, detector=StubDetector(), quiet=True)
+    part = RDB.run_sharded('stub', names[:8], 2, worker=_stub_shard_worker, checkpoint_path=ck,
+                           checkpoint_frequency=2, quiet=True)
+    assert sorted(r['file'] for r in part) == names[:8]
+    assert not os.path.exists(ck)
+    shard_files = [RDB.shard_checkpoint_path(ck, g) for g in range(2)]
+    assert all(os.path.isfile(p) for p in shard_files)
+    per_shard = [set(r['file'] for r in RDB.load_checkpoint(p)) for p in shard_files]
+    assert per_shard[0] == set(names[0:8:2]) and per_shard[1] == set(names[1:8:2])     # no shard saw the other's files
+    restored = RDB.load_sharded_checkpoints(ck, 2)
+    assert sorted(r['file'] for r in restored) == names[:8]
+    # resume: only the files without a result are sharded again
+    full = RDB.run_sharded('stub', names, 2, results=restored, worker=_stub_shard_worker, quiet=True)
+    assert _strip(full) == _strip(plain)
+    # (a resumed result is kept as it is, not recomputed)
+    marked = [dict(r, marker=1) for r in restored]
+    full = RDB.run_sharded('stub', names, 2, results=marked, worker=_stub_shard_worker, quiet=True)
+    assert sum(1 for r in full if r.get('marker') == 1) == 8
+
+
+def test_dead_shard_raises_instead_of_hanging(image_dir):
+    root, names = image_dir
+    import time
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='exited with code 3'):
+        RDB.run_sharded('stub', names, 2, worker=_dying_shard_worker, quiet=True)
+    assert time.time() - t0 < 60
+
+
+def test_previous_results_file_merge(image_dir, tmp_path, monkeypatch):
+    """reference run_detector_batch.py:2056-2096, :2166-2171"""
+    root, names = image_dir
+    monkeypatch.setattr(RDB.run_detector, 'load_detector', lambda *a, **k: StubDetector())
+    first = str(tmp_path / 'first.json')
+    sub = [n for n in names if '/cam0/' in n]
+    lst = str(tmp_path / 'list.json')
+    json.dump(sub, open(lst, 'w'))
+    # a first pass over cam0 only, written with paths relative to the folder
+    res = RDB.load_and_run_detector_batch('stub', sub, detector=StubDetector(), quiet=True)
+    RDB.write_results_to_file(res, first, relative_path_base=str(root), detector_file='md_v5a.0.0.pt')
+    for im in json.load(open(first))['images']:
+        assert not os.path.isabs(im['file'])
+    seen = []
+    orig = RDB.load_and_run_detector_batch
+
+    def spy(model_file, image_file_names, **kw):
+        seen.extend(image_file_names)
+        return orig(model_file, image_file_names, **kw)
+    monkeypatch.setattr(RDB, 'load_and_run_detector_batch', spy)
+    out = str(tmp_path / 'second.json')
+    RDB.main(['stub', str(root), out, '--output_relative_filenames', '--previous_results_file', first, '--quiet'])
+    assert sorted(seen) == sorted(n for n in names if n not in sub)           # cam0 was not processed again
+    merged = json.load(open(out))
+    monkeypatch.setattr(RDB, 'load_and_run_detector_batch', orig)
+    plain = str(tmp_path / 'plain.json')
+    RDB.main(['stub', str(root), plain, '--output_relative_filenames', '--quiet'])
+    want = json.load(open(plain))
+    assert merged['images'] == want['images']
+    with pytest.raises(AssertionError, match='relative paths'):
+        RDB.main(['stub', str(root), out, '--previous_results_file', first])
+    RDB.main(['stub', str(root), out, '--output_relative_filenames', '--overwrite_handling', 'skip'])
+    with pytest.raises(Exception, match='exists'):
+        RDB.main(['stub', str(root), out, '--output_relative_filenames', '--overwrite_handling', 'error'])
+
+
+class _ModeRecordingStub(StubDetector):
+    compatibility_mode = 'modern'
+
+    def __init__(self):
+        super().__init__()
+        self.seen = []
+
+    def generate_detections_one_batch(self, imgs, names, **kw):
+        self.seen.extend(imgs)
+        return super().generate_detections_one_batch(imgs, names, **kw)
+
+
+def test_preprocess_queue_letterboxes_in_the_detectors_compatibility_mode(image_dir):
+    """the producers' preprocessor is built from the consumer's options (reference _producer_func :143-152): under
+    compatibility_mode=modern the preprocessed dicts carry the modern geometry ('resized_shape'), not the classic one"""
+    root, names = image_dir
+    from megadetector_amd.detector import HIPDetector
+    for mode in ('modern', 'classic'):
+        det = _ModeRecordingStub()
+        det.compatibility_mode = mode
+        RDB.load_and_run_detector_batch('stub', names, detector=det, quiet=True, use_image_queue=True, batch_size=3,
+                                        preprocess_on_image_queue=True, loader_workers=2,
+                                        detector_options={'compatibility_mode': mode})
+        assert det.seen and all(isinstance(d, dict) for d in det.seen)
+        want = HIPDetector('synthetic', {'preprocess_only': True, 'compatibility_mode': mode})
+        for d in det.seen:
+            ref = want.preprocess_image(d['img_original'], image_id=d['file'])
+            assert ('resized_shape' in d) == (mode == 'modern') == ('resized_shape' in ref)
+            assert d['img_processed'].geometry == ref['img_processed'].geometry
+            assert d['target_shape'] == ref['target_shape']
+
+
+def test_user_image_size_reaches_the_device_capacity(image_dir, monkeypatch):
+    root, names = image_dir
+    got = {}
+
+    def fake_load(model_file, force_model_download=False, detector_options=None, verbose=False):
+        got.update(detector_options or {})
+        return StubDetector()
+    monkeypatch.setattr(RDB.run_detector, 'load_detector', fake_load)
+    RDB.load_and_run_detector_batch('stub', names[:2], image_size=1600, quiet=True)
+    assert got.get('max_image_size') == 1600
+    got.clear()
+    RDB.load_and_run_detector_batch('stub', names[:2], image_size=640, quiet=True)
+    assert 'max_image_size' not in got

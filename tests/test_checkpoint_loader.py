@@ -75,3 +75,61 @@ def test_refuses_foreign_classes(tmp_path):
     with pytest.raises((pickle.UnpicklingError, RuntimeError, Exception)) as ei:
         weights_io.load_checkpoint(p)
     assert 'refusing' in str(ei.value) or 'posix' in str(ei.value) or 'nt' in str(ei.value)
+
+
+def test_oracle_forward_equals_independent_module_at_x6_width(tmp_path):
+    """
+    The oracle's functional forward (oracle/yolov5.py: the checker of every conv-stack parity test) against a second,
+    independently written implementation -- tests/fake_yolov5.py's nn.Module -- on the topology BASELINE.json names
+    (YOLOv5x6, widths 80..1280, C3 depths 4/8/12/4, K up to 11520), BatchNorm statistics not trivial, through a
+    checkpoint file.  Both are restatements of the published architecture (the yolov5 package is not available
+    offline), so this pins the oracle against a second reading, not against upstream.
+    """
+    yaml = yolo_yaml.YOLOV5X6_MD
+    # gain 1.3: with the default 1.75 this depth amplifies fp32 re-association noise ~4x per head C3 (2e-2 at layer 32)
+    model = FY.build_model(yaml, seed=5, gain=1.3)
+    path = str(tmp_path / 'fake_x6.pt')
+    FY.save_checkpoint(model, path)
+    ref_model = model.half().float()
+    x = torch.rand(1, 3, 128, 192, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        ref_pred = ref_model(x)
+    FY.uninstall()
+    W = weights_io.load_checkpoint(path)
+    assert W.max_stride == 64 and W.yaml['nc'] == 3
+    assert sum(1 for k in W.weights if k.endswith('.weight')) == 163          # 159 Conv modules + 4 Detect convs (SURVEY.md section 8(d): 163 convs)
+    keep = {}
+    pred, _ = PU.oracle_forward(W, x, emulate_bf16=False, keep=keep)
+    assert pred.shape == ref_pred.shape == (1, 3 * (16 * 24 + 8 * 12 + 4 * 6 + 2 * 3), 8)
+    np.testing.assert_allclose(pred[..., :4].numpy(), ref_pred[..., :4].numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(pred[..., 4:].numpy(), ref_pred[..., 4:].numpy(), rtol=0, atol=5e-4)
+    # and layer by layer (hooks on the module): the two implementations agree on every intermediate tensor
+    outs = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, k=m.i: outs.__setitem__(k, o)) for m in ref_model.model[:-1]]
+    with torch.no_grad():
+        ref_model(x)
+    for h in hooks:
+        h.remove()
+    for i, t in keep.items():
+        emax, emean = PU.rel_err(t.numpy(), outs[i].numpy())
+        assert emax < 2e-3 and emean < 2e-4, (i, emax, emean)
+
+
+def test_refuses_callables_inside_allowed_namespaces(tmp_path):
+    """the allow-list names exact (module, name) pairs: torch.* and numpy.* as namespaces also hold loaders a
+    crafted file could REDUCE"""
+    import pickle
+
+    class ViaTorchHub:
+        def __reduce__(self):
+            return (torch.hub.load, ('x/y', 'z'))
+
+    class ViaNumpyLoad:
+        def __reduce__(self):
+            return (np.load, ('/nonexistent.npy',))
+    for i, obj in enumerate((ViaTorchHub(), ViaNumpyLoad())):
+        p = str(tmp_path / 'evil{}.pt'.format(i))
+        torch.save({'model': obj}, p)
+        with pytest.raises(Exception) as ei:
+            weights_io.load_checkpoint(p)
+        assert 'refusing' in str(ei.value), str(ei.value)

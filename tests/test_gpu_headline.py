@@ -1,0 +1,164 @@
+"""
+GPU parity tests of the HEADLINE configuration (BASELINE.json configs[1]): the MDv5a topology (YOLOv5x6, widths
+80..1280, K up to 11520, channel-group tails 80 = 64+16 / 160 = 2*64+32 / 480 = 7*64+32) with the SHIPPED tile table,
+against the oracle -- reference megadetector/detection/pytorch_detector.py:1313 (`self.model(batch)[0]`) on the
+module built at :957.  The toy networks of tests/test_gpu_parity.py never reach these shapes.
+
+  * 640x640, two images: every layer against the storage-emulating oracle, with every conv forced to the tile the
+    table holds for batch 32 at 1280x1280 (the benchmarked launch configuration), and bit-identical to the tiles the
+    table picks on its own for this batch;
+  * 1280x1280, one image, through the detector seam: predictions against the oracle within the layer tolerances,
+    NMS + rescale + formatting exact on the HIP predictions;
+  * the same at 640x640 for fp16 storage (the detector's default storage type) with its 8x tighter tolerances.
+
+Tolerances: tests/test_gpu_parity.py (LAYER_*_TOL for bf16, F16_* for fp16).
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity_util as PU
+from test_gpu_parity import LAYER_MAX_TOL, LAYER_MEAN_TOL, F16_LAYER_MAX_TOL, F16_LAYER_MEAN_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _identity_geoms(images):
+    return [(im.shape[0], im.shape[1], im.shape[0], im.shape[1], 0, 0) for im in images]
+
+
+def _table_entries(ctx):
+    path = ctx.TUNED_PATH
+    if ctx.dtype != 'bf16':
+        alt = path.replace('.json', '_{}.json'.format(ctx.dtype))
+        path = alt if os.path.exists(alt) else path
+    return json.load(open(path))['entries']
+
+
+def force_batch32_tiles(ctx, n, h, w):
+    """
+    Forces every conv op to the configuration the shipped table holds for it at batch 32 / 1280x1280 (matched on
+    the layer geometry N, K, taps, stride, residual; the entry whose per-image M is nearest), i.e. the kernels
+    bench.py's step launches.  Returns {op index: configuration name}.
+    """
+    by_name = {ctx.conv_cfg_name(c): c for c in range(ctx.num_conv_cfgs())}
+    entries = [e for e in _table_entries(ctx) if int(e.get('batch', 32)) == 32]
+    forced = {}
+    for o in ctx.op_infos():
+        if o['kind'] != 0:
+            continue
+        m_img = o['m'] / n
+        best = None
+        for e in entries:
+            if (e['n'], e['k'], e['ntaps'], e['stride'], e['has_res']) != (o['n'], o['k'], o['ntaps'], o['stride'], o['has_res']):
+                continue
+            cfg = by_name.get(e.get('name'), e['cfg'])
+            if not ctx.op_supports_cfg(o['op'], cfg):
+                continue
+            r = max(e['m'] / 32 / m_img, m_img / (e['m'] / 32))
+            if best is None or r < best[0]:
+                best = (r, cfg)
+        if best is not None:
+            ctx.set_op_cfg(o['op'], best[1])
+            forced[o['op']] = ctx.conv_cfg_name(best[1])
+    return forced
+
+
+def _layers_against_oracle(ctx, W, imgs, hh, ww, emulate, max_tol, mean_tol):
+    x, _ = PU.oracle_input(imgs, max(hh, ww), 64)
+    assert tuple(x.shape[2:]) == (hh, ww)
+    keep = {}
+    pred_ref, _ = PU.oracle_forward(W, x, emulate_bf16=emulate, keep=keep)
+    n = len(imgs)
+    rows = []
+    for i in sorted(keep):
+        emax, emean = PU.rel_err(ctx.read_layer(i, n), keep[i].numpy())
+        rows.append((i, emax, emean))
+    bad = [t for t in rows if t[1] > max_tol or t[2] > mean_tol]
+    worst = (max(t[1] for t in rows), max(t[2] for t in rows))
+    assert not bad, 'layers out of tolerance (layer, max, mean): {}'.format(bad)
+    pred = ctx.read_predictions(n)
+    assert pred.shape == tuple(pred_ref.shape)
+    e_box = PU.rel_err(pred[..., :4], pred_ref[..., :4].numpy())
+    e_conf = float(np.abs(pred[..., 4:] - pred_ref[..., 4:].numpy()).max())
+    return worst, e_box, e_conf, pred, pred_ref
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_headline_topology_every_layer_with_the_benchmarked_tiles(dtype):
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    HH = WW = 640
+    ctx = HipContext(W, device=0, dtype=dtype, max_batch=2, max_h=HH, max_w=WW)
+    try:
+        imgs = PU.structured_images(2, HH, WW, seed=91)
+        ctx.preprocess(imgs, _identity_geoms(imgs), HH, WW)
+        ctx.forward(2, HH, WW)                       # the table's own choice for this batch
+        own = ctx.read_predictions(2).copy()
+        own_cfgs = {o['op']: o['cfg'] for o in ctx.op_infos() if o['kind'] == 0}
+        forced = force_batch32_tiles(ctx, 2, HH, WW)
+        n_convs = sum(1 for o in ctx.op_infos() if o['kind'] == 0)
+        assert n_convs == 152 and len(forced) == n_convs, (n_convs, len(forced))
+        ctx.forward(2, HH, WW)
+        ran = {o['op']: ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['kind'] == 0}
+        assert ran == forced                                         # the ops really ran the benchmarked kernels
+        used = sorted(set(ran.values()))
+        print('{}: benchmarked tile configurations in use: {}'.format(dtype, used))
+        # kernel families of the benchmarked step: row-segment (v5 / v6), second-generation implicit GEMM (v2),
+        # first-generation implicit GEMM (stem, Detect, N = 80 layers)
+        assert any(u.startswith(('v5:', 'v6:')) for u in used), used
+        assert any(u.startswith('v2:') for u in used), used
+        assert any(not u.startswith('v') for u in used), used
+        emulate = True if dtype == 'bf16' else 'fp16'
+        tol = (LAYER_MAX_TOL, LAYER_MEAN_TOL) if dtype == 'bf16' else (F16_LAYER_MAX_TOL, F16_LAYER_MEAN_TOL)
+        worst, e_box, e_conf, pred, _ = _layers_against_oracle(ctx, W, imgs, HH, WW, emulate, *tol)
+        print('{}: worst layer error max {:.2e} mean {:.2e}; predictions: box {:.2e}/{:.2e}, conf {:.2e}'.format(
+            dtype, worst[0], worst[1], e_box[0], e_box[1], e_conf))
+        assert e_box[0] < tol[0] and e_box[1] < tol[1]
+        assert e_conf < (2e-2 if dtype == 'bf16' else 3e-3)
+        # tiles of one summation-order family give bit-identical results: where the table's own choice for batch 2
+        # and the batch-32 choice are of the same family for every op, the predictions are the same bits
+        same_family = all(ctx.cfg_is_bitwise(o['cfg']) == ctx.cfg_is_bitwise(own_cfgs[o['op']])
+                          for o in ctx.op_infos() if o['kind'] == 0)
+        if same_family:
+            np.testing.assert_array_equal(pred, own)
+    finally:
+        ctx.close()
+
+
+def test_headline_configuration_one_full_size_image_through_the_detector():
+    """1280x1280 (the benchmarked image size), MDv5a topology, benchmarked tiles, detector seam."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.detector import HIPDetector
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    det = HIPDetector(W, {'batch_size': 2, 'dtype': 'bf16'})
+    ctx = det._ctx
+    S = 1280
+    im = PU.structured_images(1, S, S, seed=93)[0]
+    thr = 1e-5
+    first = det.generate_detections_one_image(im, 'full.jpg', detection_threshold=thr)
+    assert 'failure' not in first
+    forced = force_batch32_tiles(ctx, 1, S, S)
+    assert len(forced) == 152
+    res = det.generate_detections_one_image(im, 'full.jpg', detection_threshold=thr)
+    assert 'failure' not in res
+    ran = {o['op']: ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['kind'] == 0}
+    assert ran == forced
+    pred_hip = ctx.read_predictions(1)
+    assert pred_hip.shape == (1, 102000, 8) and np.isfinite(pred_hip).all()
+    x, infos = PU.oracle_input([im], S, 64)
+    # exact: the reference's NMS / scale_coords / formatting statements applied to the HIP predictions
+    ref_same = PU.oracle_detections(torch.from_numpy(pred_hip), infos, (S, S), thr)[0]
+    assert res['detections'] == ref_same['detections']
+    assert res['max_detection_conf'] == ref_same['max_detection_conf']
+    # tolerance: the conv stack against the bf16-emulating oracle
+    pred_ref, _ = PU.oracle_forward(W, x, emulate_bf16=True)
+    e_box = PU.rel_err(pred_hip[..., :4], pred_ref[..., :4].numpy())
+    e_conf = float(np.abs(pred_hip[..., 4:] - pred_ref[..., 4:].numpy()).max())
+    print('1280x1280: box {:.2e}/{:.2e}, conf {:.2e}, {} detections'.format(e_box[0], e_box[1], e_conf, len(res['detections'])))
+    assert e_box[0] < LAYER_MAX_TOL and e_box[1] < LAYER_MEAN_TOL and e_conf < 2e-2

@@ -35,6 +35,9 @@ def main():
                     help='existing table (measured at the canonical batch size): only configurations of the same kernel '
                          'family (same fp32 summation order) as its entry for the layer are tried, so that an '
                          'image\'s result does not depend on the batch size it is processed at')
+    ap.add_argument('--only', default=None,
+                    help='comma-separated name prefixes (e.g. "v6:,v5:"): only these configurations are measured against '
+                         'the configuration the current table selects (a short re-tune after adding a kernel family)')
     args = ap.parse_args()
 
     import torch
@@ -45,8 +48,13 @@ def main():
     S = max(HH, WW)
     W = weights_io.synthetic_weights(getattr(yolo_yaml, args.model), seed=0)
     ctx = HipContext(W, device=0, dtype=args.dtype, max_batch=B, max_h=S, max_w=S)
-    ctx.load_tuned('/nonexistent')      # measure against the heuristic, not an older table
-    ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
+    only = None
+    if args.only:
+        pre = tuple(p for p in args.only.split(',') if p)
+        only = {c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith(pre)}
+    else:
+        ctx.load_tuned('/nonexistent')      # measure against the heuristic, not an older table
+        ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
     x = torch.randint(0, 256, (B, HH, WW, 3), dtype=torch.uint8, device='cuda')
     ctx.preprocess([int(x[i].data_ptr()) for i in range(B)], [(HH, WW, HH, WW, 0, 0)] * B, HH, WW)
     ctx.forward(B, HH, WW)                     # real activations in every buffer
@@ -71,6 +79,9 @@ def main():
             ms = []
             fam = canon.get((o['n'], o['k'], o['ntaps'], o['stride'], o['has_res'], o['m'] // B))
             for cfg in range(ncfg):
+                if only is not None and cfg not in only and cfg != o['cfg']:
+                    ms.append(float('inf'))
+                    continue
                 if fam is not None and bool(ctx.cfg_is_bitwise(cfg)) != fam[0]:
                     ms.append(float('inf'))
                     continue
@@ -84,7 +95,7 @@ def main():
         b = int(np.argmin(ms))
         tf = [o['flops'] / (t * 1e-3) / 1e12 if np.isfinite(t) else 0.0 for t in ms]
         entries[sig] = dict(m=sig[0], n=sig[1], k=sig[2], ntaps=sig[3], stride=sig[4], has_res=sig[5], cfg=b,
-                            batch=B, ms=round(ms[b], 5), tflops=round(tf[b], 1))
+                            batch=B, ms=round(ms[b], 5), tflops=round(tf[b], 1), name=ctx.conv_cfg_name(b))
         lines.append('{:34s} M={:8d} N={:5d} K={:6d} default={:2d} best={:2d} {:8.3f} ms {:7.1f} TF/s | '.format(
             o['name'], o['m'], o['n'], o['k'], o['cfg'], b, ms[b], tf[b]) +
             ' '.join('{:6.1f}'.format(t) for t in tf))
@@ -97,7 +108,7 @@ def main():
             data = {'entries': []}
     keep = [e for e in data.get('entries', [])
             if e.get('batch', 32) != B or (e['m'], e['n'], e['k'], e['ntaps'], e['stride'], e['has_res']) not in entries]
-    data = {'n_cfgs': ncfg, 'entries': keep + list(entries.values())}
+    data = {'entries': keep + list(entries.values())}
     json.dump(data, open(args.out, 'w'), indent=1, sort_keys=True)
     table = args.table or (os.path.splitext(args.out)[0] + '_{}_{}_{}x{}.txt'.format(args.model, B, HH, WW))
     with open(table, 'w') as f:
