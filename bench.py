@@ -26,14 +26,21 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0             # HBM3E peak (vendor), same guide; measured copy rate 4.75-6.3 TB/s
 GFLOP_PER_IMAGE_1280 = 831.64      # 415.82 GMAC over 163 convs
+# SURVEY.md section 8(d), algorithmic bytes per image at 1280x1280 (NOT the padded figures of the implementation):
+PRE_BYTES_PER_IMAGE = 14.75e6      # 4.92 MB uint8 read + 9.83 MB 16-bit NCHW-equivalent written
+NMS_BYTES_PER_IMAGE = 3.26e6 + 7.2e3   # 102000 x 8 fp32 read + <= 300 x 6 fp32 written
+DECODE_BYTES_PER_IMAGE = 2 * 3.26e6    # 102000 x 8 fp32 logits read + 102000 x 8 fp32 predictions written
+ACT_GB_PER_IMAGE = 1.99            # unfused activation traffic (every conv reads its input once, writes its output once)
+WEIGHT_GB = 0.28
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=1280)
     ap.add_argument('--model', default='YOLOV5X6_MD')
@@ -52,11 +59,12 @@ def parse_args():
     ap.add_argument('--lean', action='store_true',
                     help='only warm-up + timed steps (no per-stage / per-op extras): for rocprofv3 runs')
     ap.add_argument('--cpu-seconds', type=float, default=14.0)
+    ap.add_argument('--no-cpu-single-thread', action='store_true', help='skip the one-thread CPU row (one image, ~1 min)')
     ap.add_argument('--profile-out', default=None, help='write per-op timings (json) here')
     return ap.parse_args()
 
 
-def cpu_baseline(weights, size, threshold, budget_s):
+def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
     """The oracle (CPU restatement of the reference's path) timed on this host's cores."""
     import torch
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -82,10 +90,23 @@ def cpu_baseline(weights, size, threshold, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 16:
             break
-    return {'value': n / el, 'unit': 'images/s', 'cores': int(cores), 'kind': 'port',
-            'sample': '{} synthetic {}x{} images, batch 1 (CPU batch size is forced to 1 by the '
-                      'reference), oracle fp32 torch-CPU forward + NMS + formatting, {:.1f} s'.format(
-                          n, size, size, el)}
+    res = {'value': n / el, 'unit': 'images/s', 'cores': int(cores), 'kind': 'port',
+           'sample': '{} synthetic {}x{} images, batch 1 (CPU batch size is forced to 1 by the '
+                     'reference), oracle fp32 torch-CPU forward + NMS + formatting, {:.1f} s'.format(
+                         n, size, size, el)}
+    if single_thread:
+        # one thread, comparable to the published single-core figures
+        # (reference megadetector.md:358-359: 0.5-0.8 images/s per core class); ONE image bounds the cost
+        torch.set_num_threads(1)
+        try:
+            t0 = time.perf_counter()
+            one(imgs[0])
+            el1 = time.perf_counter() - t0
+        finally:
+            torch.set_num_threads(cores)
+        res['single_thread'] = {'value': 1.0 / el1, 'unit': 'images/s', 'cores': 1, 'kind': 'port',
+                                'sample': '1 synthetic {}x{} image, torch.set_num_threads(1), {:.1f} s'.format(size, size, el1)}
+    return res
 
 
 def main():
@@ -146,6 +167,11 @@ def main():
     nms_s = torch.cuda.Stream()
     fwd_done = [torch.cuda.Event() for _ in range(4)]
     nms_done = [None] * 4
+    # live per-stage timing (roofline.stages): event pairs on the stream each stage is launched on
+    RING = 16
+    ev_pre = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(RING)]
+    ev_nms = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(RING)]
+    stage_live = {'on': False, 'steps': []}
     if args.host_fed:
         # PCIe-inclusive variant: the batches live in pinned host memory; every step copies its batch
         # into one of two device buffers on a copy stream while the previous step computes
@@ -168,7 +194,11 @@ def main():
         ctx.forward(B, Hn, Wn, stream=compute_stream)
         fwd_done[k].record(comp_s)
         nms_s.wait_event(fwd_done[k])
+        if stage_live['on']:
+            ev_nms[i % RING][0].record(nms_s)
         ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=k, stream=nms_s.cuda_stream)
+        if stage_live['on']:
+            ev_nms[i % RING][1].record(nms_s)
         ev = torch.cuda.Event()
         ev.record(nms_s)
         nms_done[k] = ev
@@ -186,7 +216,12 @@ def main():
             consumed[k].record(comp_s)
             forward_and_nms(i)
             return
+        if stage_live['on']:
+            ev_pre[i % RING][0].record(comp_s)
         ctx.preprocess(ptr_lists[i % n_batches], geoms, Hn, Wn, stream=compute_stream)
+        if stage_live['on']:
+            ev_pre[i % RING][1].record(comp_s)
+            stage_live['steps'].append(i)
         forward_and_nms(i)
 
     def collect(i):
@@ -224,17 +259,28 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    stage_live['on'] = not args.host_fed
     barrier()
     t0 = time.perf_counter()
     out = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    stage_live['on'] = False
+    my_elapsed = elapsed
+    live_pre = [ev_pre[i % RING][0].elapsed_time(ev_pre[i % RING][1]) for i in stage_live['steps'][-RING:]]
+    live_nms = [ev_nms[i % RING][0].elapsed_time(ev_nms[i % RING][1]) for i in stage_live['steps'][-RING:]]
     fwd_ms_live = ctx.forward_times(min(args.steps, 64))
     ctx.time_forwards(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if one_gpu else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank rates (outside the timed region): exposes stragglers / NUMA effects on the first multi-GPU run
+        allt = [torch.zeros(1, dtype=torch.float64, device='cpu' if one_gpu else 'cuda') for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([my_elapsed], dtype=torch.float64, device='cpu' if one_gpu else 'cuda'))
+        per_rank = [round(B * args.steps / float(x.item()), 2) for x in allt]
+    else:
+        per_rank = [round(B * args.steps / my_elapsed, 2)]
 
     # ---- per-stage and per-kernel timing (outside the timed region) --------------------
     stages = {}
@@ -275,20 +321,32 @@ def main():
             conv_ms = float('nan')
         fwd_ms = float(np.mean(fwd_ms_live)) if len(fwd_ms_live) else float(ms.sum())
         achieved = conv_flops / (fwd_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(REPO, 'profiles', 'r1_hbm_traffic.json')
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get('key') == '{}:{}:{}'.format(args.model, B, S) and not args.src:
-                    traffic = tj.get('hbm_bytes_per_step')
-            except Exception:
-                traffic = None
+        # HBM bytes per step from the PMC counters: two separate `rocprofv3 --pmc` passes of THIS command
+        # (FETCH_SIZE, WRITE_SIZE; tools/gpu_round.sh traffic -> tools/hbm_traffic.py), committed under profiles/.
+        # It is read from the newest committed measurement of this workload, not measured in this run (counters
+        # cannot be collected from inside the process); `traffic_source` says which file.
+        traffic, traffic_source = None, None
+        if not args.src and args.dtype == 'bf16':
+            import glob
+            for tpath in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_hbm_traffic.json')), reverse=True):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get('key') == '{}:{}:{}'.format(args.model, B, S):
+                        traffic = tj.get('hbm_bytes_per_step')
+                        traffic_source = 'profiles/{} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; ' \
+                                         'FETCH_SIZE doubled per the guide\'s gfx950 note; not re-measured in this run)'.format(
+                                             os.path.basename(tpath))
+                        break
+                except Exception:
+                    pass
+        algorithmic_bytes = (ACT_GB_PER_IMAGE * B + WEIGHT_GB) * 1e9 * (Hn * Wn) / (1280.0 * 1280.0)
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                'kernel': 'conv stack of one step = {} conv launches (conv_igemm_kernel / conv_v2_kernel / '
-                          'conv_v4_kernel / conv_v5_kernel instantiations), HIP events on the launch stream around mdhip_forward in '
-                          'the timed region, mean of {} steps'.format(len(conv), len(fwd_ms_live)),
+                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+                'algorithmic_bytes_per_step': algorithmic_bytes,
+                'traffic_over_algorithmic': None if not traffic else round(traffic / algorithmic_bytes, 3),
+                'kernel': 'conv stack of one step = {} conv launches (conv_igemm_kernel / conv_v2_kernel / conv_v4_kernel / '
+                          'conv_v5_kernel / conv_v6_kernel instantiations), HIP events on the launch stream around '
+                          'mdhip_forward in the timed region, mean of {} steps'.format(len(conv), len(fwd_ms_live)),
                 'flops_per_step': conv_flops, 'kernel_ms_per_step': round(fwd_ms, 3),
                 'per_op_conv_ms_per_step': None if args.lean else round(conv_ms, 3),
                 'per_op_conv_tflops': None if args.lean else round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
@@ -307,6 +365,27 @@ def main():
                 'ms_per_step': round(top[1][1], 3), 'avg_launch_us': round(top[1][1] / top[1][0] * 1e3, 2),
                 'flops_per_step': top[1][2], 'achieved_tflops': round(top[1][2] / (top[1][1] * 1e-3) / 1e12, 2),
                 'frac': round(top[1][2] / (top[1][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        # per-stage HBM rooflines (north_star: "rocprof HBM GB/s for preprocess/NMS"): algorithmic bytes of SURVEY.md
+        # section 8(d) / duration of the stage's kernels measured live (HIP events on the stream the stage is launched
+        # on, timed region; the NMS pair also covers the D2H of the <= 300 x 6 results) -- decode from the per-op events
+        def stage(bytes_per_image, ms_list, note):
+            if not len(ms_list):
+                return None
+            ms_ = float(np.mean(ms_list))
+            gbps = bytes_per_image * B / (ms_ * 1e-3) / 1e9
+            return {'bound': 'hbm', 'bytes': bytes_per_image * B, 'ms': round(ms_, 4), 'achieved': round(gbps, 1),
+                    'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': round(gbps / PEAK_HBM_GBPS, 4), 'how': note}
+        scale_px = (Hn * Wn) / (1280.0 * 1280.0)
+        src_bytes = H0 * W0 * 3 + Hn * Wn * 3 * 2           # uint8 source read + 16-bit network input written
+        roof['stages'] = {
+            'preprocess': stage(src_bytes, live_pre, 'letterbox_s2d_kernel, live events, {} steps'.format(len(live_pre))),
+            'nms': stage(NMS_BYTES_PER_IMAGE * scale_px, live_nms,
+                         'nms kernels + D2H of the results, live events on the NMS stream, {} steps'.format(len(live_nms))),
+            'decode': None if args.lean else stage(
+                DECODE_BYTES_PER_IMAGE * scale_px, [float(sum(ms[o['op']] for o in infos if o['kind'] == 3))],
+                'detect_decode_kernel x{} levels, per-op events outside the timed region'.format(
+                    sum(1 for o in infos if o['kind'] == 3))),
+        }
         if args.model == 'YOLOV5X6_MD' and (Hn, Wn) == (1280, 1280):
             assert abs(conv_flops / B / 1e9 - GFLOP_PER_IMAGE_1280) < 0.05, conv_flops / B / 1e9
         if args.profile_out and not args.lean:
@@ -319,7 +398,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(weights, S, args.threshold, args.cpu_seconds)
+        cpu = cpu_baseline(weights, S, args.threshold, args.cpu_seconds, single_thread=not args.no_cpu_single_thread)
 
     if rank == 0:
         total_images = world * B * args.steps
@@ -344,12 +423,12 @@ def main():
                              '{0}x{4} letterbox, batch {1} per GPU, uint8 RGB inputs resident in HBM, seeded '
                              'synthetic weights (no checkpoint available offline), NMS threshold {2}').format(
                                  Hn, B, args.threshold, GFLOP_PER_IMAGE_1280 * Hn * Wn / (1280.0 * 1280.0), Wn, args.dtype),
-                'model': args.model, 'batch_per_gpu': B, 'image_size': S,
                 'parallelism': 'image queue sharded over {} GPU(s), one process per GPU, no collectives'.format(world),
             },
             'roofline': roof,
             'cpu_baseline': cpu,
             'stages': stages,
+            'per_rank_images_per_s': per_rank,
         }
         print(json.dumps(line))
     if dist is not None:

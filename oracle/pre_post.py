@@ -465,33 +465,30 @@ def format_detections(det, batch_hw, img_original_shape, scaling_shape, detectio
 # the reference's definition of "same results" (reference md_tests.py:96-100,124,418-531)
 # --------------------------------------------------------------------------------------
 
-def compare_detection_lists(dets_a, dets_b, iou_match=0.85):
+def compare_detection_lists(dets_a, dets_b, iou_match=0.85, bidirectional=True):
     """
-    Returns (max_conf_err, max_coord_err) between two detection lists, matching same-category
-    boxes with IoU >= iou_match; an unmatched box contributes its own confidence as error
-    (reference md_tests.py:418-531).
+    Returns (max_conf_err, max_coord_err) between two detection lists, following reference md_tests.py:418-531
+    statement for statement: every detection of A is matched to the same-category detection of B with the highest
+    IoU >= iou_match (matches may be many-to-one); |d conf| and max |d coord| over the matches; an unmatched detection
+    contributes its own confidence as confidence error; then the same with the arguments reversed.
+    Pinned against the real function by tests/golden/compare_kat.json (tests/test_oracle_golden.py).
     """
-    max_conf_err, max_coord_err = 0.0, 0.0
-    used = set()
+    max_conf_err, max_coord_err = 0, 0
     for da in dets_a:
-        best, best_iou = None, -1.0
-        for j, db in enumerate(dets_b):
-            if j in used or db['category'] != da['category']:
+        best, best_iou = None, -1
+        for db in dets_b:
+            if db['category'] != da['category']:
                 continue
-            try:
-                iou = get_iou(da['bbox'], db['bbox'])
-            except AssertionError:
-                iou = 1.0 if da['bbox'] == db['bbox'] else 0.0
+            iou = get_iou(da['bbox'], db['bbox'])
             if iou >= iou_match and iou > best_iou:
-                best, best_iou = j, iou
+                best, best_iou = db, iou
         if best is None:
-            max_conf_err = max(max_conf_err, da['conf'])
+            if da['conf'] > max_conf_err:
+                max_conf_err = da['conf']
             continue
-        used.add(best)
-        db = dets_b[best]
-        max_conf_err = max(max_conf_err, abs(da['conf'] - db['conf']))
-        max_coord_err = max(max_coord_err, max(abs(p - q) for p, q in zip(da['bbox'], db['bbox'])))
-    for j, db in enumerate(dets_b):
-        if j not in used:
-            max_conf_err = max(max_conf_err, db['conf'])
+        max_conf_err = max(max_conf_err, abs(da['conf'] - best['conf']))
+        max_coord_err = max(max_coord_err, max(abs(p - q) for p, q in zip(da['bbox'], best['bbox'])))
+    if bidirectional:
+        rc, rx = compare_detection_lists(dets_b, dets_a, iou_match, bidirectional=False)
+        max_conf_err, max_coord_err = max(max_conf_err, rc), max(max_coord_err, rx)
     return max_conf_err, max_coord_err

@@ -28,10 +28,21 @@ def main():
     FY.save_checkpoint(model, '/tmp/acc_fake.pt')
     FY.uninstall()
     cases.append(('checkpoint (fake_yolov5 S6)', weights_io.load_checkpoint('/tmp/acc_fake.pt')))
-    hh, ww = 384, 640
+    if '--x6' in sys.argv:
+        # the headline topology: seeded weights as bench.py uses them, and checkpoint files with non-trivial
+        # BatchNorm statistics at two conditioning levels (gain 1.3: a perturbation does not grow through the head,
+        # like a trained network; 1.75: it grows ~4x per head C3 -- tests/fake_yolov5.build_model)
+        cases = [('synthetic YOLOV5X6_MD (bench weights)', weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0))]
+        for gain in (1.3, 1.75):
+            model = FY.build_model(yolo_yaml.YOLOV5X6_MD, seed=7, gain=gain)
+            FY.save_checkpoint(model, '/tmp/acc_fake_x6.pt')
+            del model
+            FY.uninstall()
+            cases.append(('checkpoint x6 gain {}'.format(gain), weights_io.load_checkpoint('/tmp/acc_fake_x6.pt')))
+    hh, ww = (640, 640) if '--x6' in sys.argv else (384, 640)
     imgs = PU.structured_images(2, hh, ww, seed=71)
     x, _ = PU.oracle_input(imgs, ww, 64)
-    print('{:30s} {:5s} {:>12s} {:>14s} {:>12s} {:>12s}'.format('weights', 'dtype', 'max|dconf|', 'max|dconf|>0.1', 'box rel max', 'box rel mean'))
+    print('{:38s} {:5s} {:>12s} {:>14s} {:>12s} {:>12s}'.format('weights', 'dtype', 'max|dconf|', 'max|dconf|>0.1', 'box rel max', 'box rel mean'))
     for label, W in cases:
         p32, _ = PU.oracle_forward(W, x, emulate_bf16=False)
         p32 = p32.numpy()
@@ -44,9 +55,12 @@ def main():
             d = np.abs(got[..., 4:] - p32[..., 4:])
             score = (p32[..., 4:5] * p32[..., 5:]).max(-1)
             hi = score > 0.1
+            mid = score > 0.005
             e = PU.rel_err(got[..., :4], p32[..., :4])
-            print('{:30s} {:5s} {:12.5f} {:14.5f} {:12.2e} {:12.2e}   ({} confident anchors)'.format(
-                label, dtype, d.max(), d[hi].max() if hi.any() else float('nan'), e[0], e[1], int(hi.sum())))
+            sc_got = (got[..., 4:5] * got[..., 5:]).max(-1)
+            print('{:38s} {:5s} {:12.5f} {:14.5f} {:12.2e} {:12.2e}   ({} anchors > 0.1, {} > 0.005; max |d score| over those: {:.5f})'.format(
+                label, dtype, d.max(), d[hi].max() if hi.any() else float('nan'), e[0], e[1], int(hi.sum()), int(mid.sum()),
+                float(np.abs(sc_got - score)[mid].max()) if mid.any() else float('nan')))
 
 
 if __name__ == '__main__':

@@ -137,3 +137,30 @@ def test_resize_linear_identity_and_constant():
     ramp = np.array([[[0, 0, 0], [200, 200, 200]]], dtype=np.uint8)
     up = O.resize_linear_u8(ramp, 4, 1)
     assert up[0, :, 0].tolist() == [0, 50, 150, 200]
+
+
+def test_detection_list_comparison_rule_matches_the_reference():
+    """md_tests.py:418-531 compare_detection_lists: outputs of the REAL function (tests/golden/gen_compare_golden.py)
+    against the two restatements -- the oracle's (used by the parity tests) and tools/parity_real.py's (the
+    real-weights harness)"""
+    import importlib.util
+    kat = json.load(open(os.path.join(GOLDEN, 'compare_kat.json')))
+    assert kat['iou_threshold'] == 0.85 and kat['max_conf_error'] == 0.005 and kat['max_coord_error'] == 0.001
+    spec = importlib.util.spec_from_file_location('parity_real', os.path.join(os.path.dirname(GOLDEN), '..', 'tools', 'parity_real.py'))
+    PR = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(PR)
+    assert (PR.IOU_MATCH, PR.MAX_CONF_ERROR, PR.MAX_COORD_ERROR) == (0.85, 0.005, 0.001)
+    n_nonzero = 0
+    for c in kat['cases']:
+        want = (c['max_conf_error'], c['max_coord_error'])
+        assert O.compare_detection_lists(c['a'], c['b']) == want
+        assert PR.compare_detection_lists(c['a'], c['b']) == want
+        n_nonzero += want[0] > 0
+    assert n_nonzero >= 20
+    # compare_results (md_tests.py:533-640) on whole files: failures must agree, worst image reported
+    a = {'images': [{'file': 'x/1.jpg', 'detections': kat['cases'][1]['a']}, {'file': 'x\\\\2.jpg', 'failure': 'f', 'detections': None}]}
+    b = {'images': [{'file': 'x/1.jpg', 'detections': kat['cases'][1]['b']}, {'file': 'x/2.jpg', 'failure': 'f'}]}
+    b['images'][1]['file'] = 'x/2.jpg'
+    a['images'][1]['file'] = 'x\\2.jpg'
+    c, cf, x, xf = PR.compare_results(a, b)
+    assert (c, x) == (kat['cases'][1]['max_conf_error'], kat['cases'][1]['max_coord_error']) and cf == 'x/1.jpg'
