@@ -59,6 +59,10 @@ def _device_ordinal(device):
     raise ValueError('HIPDetector needs a GPU device ("cuda:N"), got {}'.format(device))
 
 
+# storage type when detector_options does not name one (see HIPDetector.__init__)
+DEFAULT_DTYPE = 'fp16'
+
+
 class HIPDetector:
 
     def __init__(self, model_path, detector_options=None, verbose=False):
@@ -66,7 +70,12 @@ class HIPDetector:
         model_path: a YOLOv5 .pt checkpoint (md_v5a.0.0.pt ...), a YoloWeights object, or the
         string 'synthetic[:yaml_name[:seed]]' for seeded weights on the MDv5 topology.
         detector_options keys honoured: force_cpu (must be false), use_model_native_classes,
-        compatibility_mode, preprocess_only, device, batch_size, max_image_size.
+        compatibility_mode, preprocess_only, device, batch_size, max_image_size, dtype.
+        dtype: storage type of activations and packed weights (accumulation is fp32 either way).  Default 'fp16':
+        |d conf| against the fp32 evaluation the reference performs stays below the reference's own bar between
+        environments (0.005-0.01, md_tests.py:96-100,1779) with an 8x margin on every model measured
+        (profiles/r2a_accuracy_x6.txt); 'bf16' is the throughput configuration BASELINE.json names (3 % faster,
+        8 significant bits).
         """
         opts = dict(detector_options or {})
         self.use_model_native_classes = parse_bool_string(opts.get('use_model_native_classes', False))
@@ -125,7 +134,7 @@ class HIPDetector:
         max_size = -(-max_size // weights.max_stride) * weights.max_stride
         if 'classic' not in compat:
             max_size += weights.max_stride      # the modern target shape is ceil(size / stride + 0.5) * stride
-        self._ctx = HipContext(weights, device=_device_ordinal(device), dtype=opts.get('dtype', 'bf16'),
+        self._ctx = HipContext(weights, device=_device_ordinal(device), dtype=opts.get('dtype') or DEFAULT_DTYPE,
                                max_batch=self.max_batch, max_h=max_size, max_w=max_size)
         self.model = self._ctx
 

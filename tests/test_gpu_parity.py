@@ -41,6 +41,10 @@ LAYER_MEAN_TOL = 8e-3
 # with bf16 activation storage on these weights -- DESIGN.md section 6 discusses it (and the fp16 option).
 E2E_CONF_TOL_BF16_ORACLE = 0.04    # oracle with the same bf16 storage rounding, different summation order
 E2E_CONF_TOL_FP32_ORACLE = 0.08    # fp32 oracle (= what the reference computes)
+# The detector's DEFAULT storage type is fp16 (megadetector_amd/detector.py DEFAULT_DTYPE): there the bar is the
+# reference's own (md_tests.py:96-100 max_conf_error 0.005, CI 0.01 at :1779), against the fp32 oracle, on the same
+# ill-conditioned seeded weights:
+E2E_CONF_TOL_FP16 = {True: 0.005, False: 0.01}      # keyed like the loop below: storage-emulating oracle / fp32 oracle
 
 
 @pytest.fixture(scope='module')
@@ -478,11 +482,20 @@ def test_nms_properties_full_size(nms_ctx):
 # ---------------------------------------------------------------------------------------
 # end to end through the detector seam
 # ---------------------------------------------------------------------------------------
-def test_detector_end_to_end_vs_oracle():
+@pytest.mark.parametrize('dtype', [None, 'bf16'])
+def test_detector_end_to_end_vs_oracle(dtype):
+    """dtype None = the detector's default storage type (fp16), 'bf16' = the benchmarked throughput mode"""
     from megadetector_amd import weights_io, yolo_yaml
-    from megadetector_amd.detector import HIPDetector
+    from megadetector_amd.detector import HIPDetector, DEFAULT_DTYPE
     W = weights_io.synthetic_weights(yolo_yaml.YOLOV5N6_TEST, seed=1)
-    det = HIPDetector(W, {'batch_size': 4, 'max_image_size': 320})
+    opts = {'batch_size': 4, 'max_image_size': 320}
+    if dtype:
+        opts['dtype'] = dtype
+    det = HIPDetector(W, opts)
+    storage = dtype or DEFAULT_DTYPE
+    assert det._ctx.dtype == storage and DEFAULT_DTYPE == 'fp16'
+    emulation = {True: True if storage == 'bf16' else 'fp16', False: False}
+    conf_tol = {True: E2E_CONF_TOL_BF16_ORACLE, False: E2E_CONF_TOL_FP32_ORACLE} if storage == 'bf16' else E2E_CONF_TOL_FP16
     det.default_image_size = 320
     det.letterbox_stride = 64
     imgs = PU.structured_images(3, 240, 320, seed=31) + PU.structured_images(1, 300, 200, seed=32)
@@ -507,10 +520,13 @@ def test_detector_end_to_end_vs_oracle():
         assert r['max_detection_conf'] == ref_same['max_detection_conf']
         # (2) tolerance: against the oracle's own forward (bf16-emulating and fp32 = reference)
         for emulate in (True, False):
-            pred, _ = PU.oracle_forward(W, x, emulate_bf16=emulate)
+            pred, _ = PU.oracle_forward(W, x, emulate_bf16=emulation[emulate])
             e_box = PU.rel_err(pred_hip[..., :4].numpy(), pred[..., :4].numpy())
             e_conf = float(np.abs(pred_hip[..., 4:].numpy() - pred[..., 4:].numpy()).max())
-            assert e_box[0] < 5e-2 and e_box[1] < 1e-2 and e_conf < 6e-2, (emulate, e_box, e_conf)
+            if storage == 'bf16':
+                assert e_box[0] < 5e-2 and e_box[1] < 1e-2 and e_conf < 6e-2, (emulate, e_box, e_conf)
+            else:
+                assert e_box[0] < 6e-3 and e_box[1] < 1.5e-3 and e_conf < F16_CONF_TOL_FP32_ORACLE, (emulate, e_box, e_conf)
             # Greedy NMS is discontinuous at near-ties, so survivors are not compared one to one;
             # instead every confident HIP survivor must be a legitimate candidate in the oracle's
             # own predictions: same class, IoU >= 0.85 (md_tests.py:124) and |dconf| within the
@@ -533,11 +549,11 @@ def test_detector_end_to_end_vs_oracle():
                 cand = (ccls == int(row[5])) & (iou >= 0.85)
                 assert cand.any(), ('no oracle candidate for a confident HIP detection', emulate, row)
                 worst[emulate] = max(worst[emulate], float(np.abs(cbest[cand] - row[4]).min()))
-    print('end-to-end: confident survivors {} ; worst |dconf| vs bf16-emulating oracle {:.4f}, vs fp32 oracle {:.4f}'.format(
-        n_hi, worst[True], worst[False]))
+    print('end-to-end ({}): confident survivors {} ; worst |dconf| vs storage-emulating oracle {:.4f}, vs fp32 oracle {:.4f}'.format(
+        storage, n_hi, worst[True], worst[False]))
     assert n_hi[True] > 0
-    assert worst[True] <= E2E_CONF_TOL_BF16_ORACLE, worst
-    assert worst[False] <= E2E_CONF_TOL_FP32_ORACLE, worst
+    assert worst[True] <= conf_tol[True], worst
+    assert worst[False] <= conf_tol[False], worst
     # a broken image must not kill the batch (reference pytorch_detector.py:1212-1222)
     res = det.generate_detections_one_batch([imgs[0], np.zeros((4, 4), np.uint8)], ['ok.jpg', 'bad.jpg'])
     assert res[1]['failure'] == 'image access failure' and res[1]['detections'] is None
@@ -572,7 +588,10 @@ def test_checkpoint_file_through_load_detector(tmp_path):
     assert got.shape == ref_pred.shape
     e_box = PU.rel_err(got[..., :4], ref_pred[..., :4])
     e_conf = float(np.abs(got[..., 4:] - ref_pred[..., 4:]).max())
-    assert e_box[0] < 5e-2 and e_box[1] < 1e-2 and e_conf < E2E_CONF_TOL_FP32_ORACLE, (e_box, e_conf)
+    # default storage type (fp16): the reference's own bar against the module's fp32 forward
+    assert det._ctx.dtype == 'fp16'
+    print('checkpoint through load_detector: box {:.2e}/{:.2e} conf {:.2e}'.format(e_box[0], e_box[1], e_conf))
+    assert e_box[0] < 6e-3 and e_box[1] < 1.5e-3 and e_conf < 0.005, (e_box, e_conf)
     ref_same = PU.oracle_detections(torch.from_numpy(got), infos, (h, w), 1e-5)
     for r, q in zip(res, ref_same):
         assert r['detections'] == q['detections']
