@@ -456,12 +456,15 @@ struct Family {
     hipError_t (*init)();
     bool bitwise;        // false: equals the implicit-GEMM kernels up to fp32 summation order only (other K order)
     int dev_base;        // developer variant k (0, 1, ...) is addressed as  dev_base - k
+    bool f8_in;          // takes e4m3 activations (and nothing else)
+    bool f8_out;         // its epilogue can write e4m3 (ConvArgs::out_f8)
 };
 const Family g_fams[] = {
-    {conv2_num_cfgs, conv2_cfg, conv2_supports_l, conv2_launch, conv2_init, true, -1},
-    {conv4_num_cfgs, conv4_cfg, conv4_supports, conv4_launch, conv4_init, false, -201},
-    {conv5_num_cfgs, conv5_cfg, conv5_supports, conv5_launch, conv5_init, false, -301},
-    {conv6_num_cfgs, conv6_cfg, conv6_supports, conv6_launch, conv6_init, false, -401},
+    {conv2_num_cfgs, conv2_cfg, conv2_supports_l, conv2_launch, conv2_init, true, -1, false, true},
+    {conv4_num_cfgs, conv4_cfg, conv4_supports, conv4_launch, conv4_init, false, -201, false, false},
+    {conv5_num_cfgs, conv5_cfg, conv5_supports, conv5_launch, conv5_init, false, -301, false, false},
+    {conv6_num_cfgs, conv6_cfg, conv6_supports, conv6_launch, conv6_init, false, -401, false, false},
+    {conv8_num_cfgs, conv8_cfg, conv8_supports, conv8_launch, conv8_init, false, -801, true, false},
 };
 constexpr int kNumFams = (int)(sizeof(g_fams) / sizeof(g_fams[0]));
 // family and local id of a global id >= kNumV1
@@ -496,10 +499,11 @@ bool conv_cfg_is_bitwise_family(int cfg) {
 
 bool conv_supports(int cfg, const ConvArgs& a) {
     if (cfg < 0 || cfg >= conv_num_cfgs()) return false;
-    if (cfg < kNumV1) return true;                                  // the first-generation kernel takes every op
+    if (cfg < kNumV1) return !a.in_f8;                              // the first-generation kernel takes every 16-bit op
     int l = 0;
     const Family* f = find_family(cfg, &l);
-    return f && f->supports(l, a);
+    if (!f || f->f8_in != (a.in_f8 != 0) || (a.out_f8 && !f->f8_out)) return false;
+    return f->supports(l, a);
 }
 
 hipError_t conv_init() {
@@ -525,8 +529,10 @@ hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     if (cfg >= kNumV1) {
         int l = 0;
         const Family* f = find_family(cfg, &l);
-        return f ? f->launch(l, a, s) : hipErrorInvalidValue;
+        if (!f || f->f8_in != (a.in_f8 != 0) || (a.out_f8 && !f->f8_out)) return hipErrorInvalidValue;
+        return f->launch(l, a, s);
     }
+    if (a.in_f8) return hipErrorInvalidValue;
     const ConvCfg& c = g_cfgs[cfg];
     ConvArgs p = a;
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;

@@ -612,6 +612,12 @@ void fill_conv_args(mdhip_ctx* ctx, Op& op, int n, int h, int w, ConvArgs& a) {
     a.ld_res = op.has_res ? op.res.ld : 0;
     a.tiles_n = 1;
     a.dbg = nullptr;
+    a.dev_param = 0;
+    a.wgt8 = nullptr;
+    a.scale = nullptr;
+    a.k_pad8 = a.groups8 = 0;
+    a.in_f8 = a.out_f8 = 0;
+    a.out_qscale = 1.0f;
     a.wgt4 = pc.w4_off ? (const uint16_t*)(ctx->warena + pc.w4_off) : nullptr;
     a.k_pad4 = pc.k_pad4;
     a.groups = pc.groups;

@@ -34,6 +34,45 @@ __host__ __device__ inline float f16_to_f32(uint16_t h) {
     v.u = h;
     return (float)v.h;
 }
+// OCP e4m3 (fn): round to nearest even, saturating at +-448 (the hardware conversion used by the kernels is fed
+// clamped values, so both agree); NaN -> 0x7f
+__host__ __device__ inline uint8_t f32_to_e4m3(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    const uint32_t sign = (v.u >> 24) & 0x80u;
+    uint32_t a = v.u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint8_t)(sign | 0x7f);
+    if (a >= 0x43e00000u) return (uint8_t)(sign | 0x7e);            // >= 448 (incl. inf): saturate
+    if (a < 0x3a800000u) {                                          // < 2^-10: below half of the smallest subnormal 2^-9
+        return (uint8_t)sign;                                       // (2^-10 itself is a tie to even = 0)
+    }
+    const int e = (int)(a >> 23) - 127;                             // unbiased exponent, -10 .. 8
+    if (e < -6) {                                                   // subnormal range: quantum 2^-9
+        v.u = a;
+        const float q = v.f * 512.0f;                               // exact
+        // round to nearest even integer in [0, 8]
+        const float r = q + 12582912.0f;                            // 1.5 * 2^23: the add rounds to an integer, RNE
+        union { float f; uint32_t u; } w;
+        w.f = r;
+        const uint32_t m = w.u & 0xfu;                              // 0 .. 8 (8 = the smallest normal 2^-6)
+        return (uint8_t)(sign | m);
+    }
+    uint32_t mant = a & 0x7fffffu;
+    uint32_t keep = mant >> 20, rest = mant & 0xfffffu;
+    uint32_t out = ((uint32_t)(e + 7) << 3) | keep;
+    if (rest > 0x80000u || (rest == 0x80000u && (keep & 1u))) ++out;   // RNE; a carry moves into the exponent
+    if (out > 0x7eu) out = 0x7eu;
+    return (uint8_t)(sign | out);
+}
+__host__ __device__ inline float e4m3_to_f32(uint8_t h) {
+    const uint32_t s = h >> 7, e = (h >> 3) & 15u, m = h & 7u;
+    union { float f; uint32_t u; } v;
+    if (e == 15u && m == 7u) { v.u = 0x7fc00000u; return v.f; }
+    float f;
+    if (e == 0u) f = (float)m * (1.0f / 512.0f);
+    else { v.u = ((e + 120u) << 23) | (m << 20); f = v.f; }
+    return s ? -f : f;
+}
 __host__ __device__ inline uint16_t f32_to_st(float f, int f16) { return f16 ? f32_to_f16(f) : f32_to_bf16(f); }
 __host__ __device__ inline float st_to_f32(uint16_t h, int f16) { return f16 ? f16_to_f32(h) : bf16_to_f32(h); }
 
@@ -104,7 +143,17 @@ struct ConvArgs {
     // row-patch direct convolution (conv_v4.cpp): weights packed [n_rows][groups*9*64], k = (cg, r, s, c % 64)
     const uint16_t* wgt4;   // nullptr when the op has no such packing
     int k_pad4, groups;
+    // fp8 path (conv_f8.cpp; MDHIP_DTYPE_FP8): the input view holds e4m3 bytes (ld_in, C8 then count BYTES and
+    // 16-byte chunks = 16 channels), weights packed [n_rows][groups8*9*128] e4m3, k = (channel group of 128, tap,
+    // channel in group), `scale` = per-output-channel fp32 factor (activation scale x weight scale) applied to the
+    // fp32 accumulator before the bias; out_f8: the 16-bit kernels' epilogue writes e4m3(v * out_qscale) bytes
+    const uint8_t* wgt8;
+    const float*   scale;
+    int k_pad8, groups8;
+    int in_f8, out_f8;
+    float out_qscale;
     void* dbg;              // instrumentation output of the profiling variants (tools/convbench.cpp), else nullptr
+    int dev_param;          // free parameter of the developer variants (tools/convbench.cpp: env MDHIP_DEV_PARAM)
 };
 
 struct ConvCfg {
@@ -121,6 +170,7 @@ struct ConvCfg {
 //   conv4_* : row-patch direct convolution for 3x3 / stride 1 (conv_v4.cpp)
 //   conv5_* : 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp)
 //   conv6_* : the same reuse with 32x32x16 MFMA fragments and one 8-wave workgroup per CU (conv_v6.cpp)
+//   conv8_* : conv_v5's structure on e4m3 operands with the block-scaled K = 128 MFMA (conv_f8.cpp)
 // conv_launch returns hipSuccess or the launch error; conv_init raises the dynamic-LDS limits (one-off);
 // conv_cfg_is_bitwise_family is false for kernels whose result equals the others' up to fp32 summation
 // order only.
@@ -151,7 +201,12 @@ struct ConvCfg {
     const ConvCfg& conv6_cfg(int i); \
     bool conv6_supports(int cfg, const ConvArgs& a); \
     hipError_t conv6_launch(int cfg, const ConvArgs& a, hipStream_t s); \
-    hipError_t conv6_init();
+    hipError_t conv6_init(); \
+    int conv8_num_cfgs(); \
+    const ConvCfg& conv8_cfg(int i); \
+    bool conv8_supports(int cfg, const ConvArgs& a); \
+    hipError_t conv8_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv8_init();
 namespace st_bf16 {
 MDHIP_CONV_API
 }

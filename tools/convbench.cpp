@@ -79,6 +79,31 @@ __global__ void ref_conv(const uint16_t* in, const uint16_t* wgt, const float* b
     out[(size_t)m * N + n] = f32_to_bf16(v);
 }
 
+// fp8 reference: e4m3 activations [pixels][C] and weights [N][9][C] (dense, k = t*C + c), fp32 accumulation,
+// per-channel scale, bias, SiLU, residual, bf16 output
+__global__ void ref_conv_f8(const uint8_t* in, const uint8_t* wgt, const float* scale, const float* bias,
+                            const uint16_t* res, uint16_t* out, int B, int H, int W, int C, int N) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * H * W * N;
+    if (t >= total) return;
+    const int n = (int)(t % N);
+    const long long m = t / N;
+    const int ox = (int)(m % W), oy = (int)((m / W) % H), b = (int)(m / ((long long)W * H));
+    float acc = 0.f;
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) {
+            const int iy = oy - 1 + r, ix = ox - 1 + q;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+            const uint8_t* ip = in + ((size_t)(b * H + iy) * W + ix) * C;
+            const uint8_t* wp = wgt + ((size_t)n * 9 + (r * 3 + q)) * C;
+            for (int c = 0; c < C; ++c) acc += e4m3_to_f32(ip[c]) * e4m3_to_f32(wp[c]);
+        }
+    float v = acc * scale[n] + bias[n];
+    v = v / (1.0f + expf(-v));
+    if (res) v += bf16_to_f32(res[(size_t)m * N + n]);
+    out[(size_t)m * N + n] = f32_to_bf16(v);
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) {
         fprintf(stderr, "usage: convbench <shape> <iters> <cfg>...   (cfg -1 = all)\n");
@@ -96,6 +121,7 @@ int main(int argc, char** argv) {
         if (argv[i][0] == 'r') { cfgs.push_back(-201 - atoi(argv[i] + 1)); continue; } // r0, r1: v4 developer variants
         if (argv[i][0] == 't') { cfgs.push_back(-301 - atoi(argv[i] + 1)); continue; } // t0..: v5 developer variants
         if (argv[i][0] == 'u') { cfgs.push_back(-401 - atoi(argv[i] + 1)); continue; } // u0..: v6 developer variants
+        if (argv[i][0] == 'f') { cfgs.push_back(-801 - atoi(argv[i] + 1)); continue; } // f0..: fp8 developer variants
         if (argv[i][0] == 'n') {                                                        // n<prefix>: every configuration whose name starts with prefix
             for (int j = 0; j < conv_num_cfgs(); ++j) if (!strncmp(conv_cfg(j).name, argv[i] + 1, strlen(argv[i] + 1))) cfgs.push_back(j);
             continue;
@@ -161,8 +187,50 @@ int main(int argc, char** argv) {
                            sh->s, pad, k_pad, cin_pad);
         CK(hipDeviceSynchronize());
     }
-    std::vector<uint16_t> h_ref(out_elems), h_out(out_elems);
-    CK(hipMemcpy(h_ref.data(), d_ref, out_elems * 2, hipMemcpyDeviceToHost));
+    std::vector<uint16_t> h_ref16(out_elems), h_out(out_elems);
+    CK(hipMemcpy(h_ref16.data(), d_ref, out_elems * 2, hipMemcpyDeviceToHost));
+
+    // fp8 operands of the same layer (conv_f8.cpp): activations e4m3 [pixels][C], weights quantised per output
+    // channel (scale = amax / 448), packed [n_rows][groups8 * 9 * 128], k = (channel group of 128, tap, channel)
+    const bool want_f8 = sh->k == 3 && sh->s == 1 && (sh->cin % 16) == 0;
+    const int groups8 = (sh->cin + 127) / 128, k_pad8 = groups8 * 9 * 128;
+    uint8_t *d_in8 = nullptr, *d_w8 = nullptr, *d_w8dense = nullptr;
+    float* d_scale = nullptr;
+    uint16_t* d_ref8 = nullptr;
+    std::vector<uint16_t> h_ref8;
+    if (want_f8) {
+        std::vector<uint8_t> h_in8(in_elems), h_w8((size_t)n_rows * k_pad8, 0), h_w8d((size_t)sh->cout * 9 * sh->cin);
+        std::vector<float> h_scale(n_rows, 0.f);
+        for (size_t i = 0; i < in_elems; ++i) h_in8[i] = f32_to_e4m3(bf16_to_f32(h_in[i]));
+        for (int n = 0; n < sh->cout; ++n) {
+            float amax = 0.f;
+            for (int t = 0; t < 9; ++t)
+                for (int c = 0; c < sh->cin; ++c) amax = fmaxf(amax, fabsf(bf16_to_f32(h_w[(size_t)n * k_pad + t * cin_pad + c])));
+            const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+            h_scale[n] = sc;
+            for (int t = 0; t < 9; ++t)
+                for (int c = 0; c < sh->cin; ++c) {
+                    const uint8_t q = f32_to_e4m3(bf16_to_f32(h_w[(size_t)n * k_pad + t * cin_pad + c]) / sc);
+                    h_w8d[((size_t)n * 9 + t) * sh->cin + c] = q;
+                    h_w8[(size_t)n * k_pad8 + ((c / 128) * 9 + t) * 128 + (c % 128)] = q;
+                }
+        }
+        CK(hipMalloc(&d_in8, in_elems + 4096));
+        CK(hipMalloc(&d_w8, h_w8.size()));
+        CK(hipMalloc(&d_w8dense, h_w8d.size()));
+        CK(hipMalloc(&d_scale, n_rows * 4));
+        CK(hipMalloc(&d_ref8, out_elems * 2));
+        CK(hipMemcpy(d_in8, h_in8.data(), in_elems, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_w8, h_w8.data(), h_w8.size(), hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_w8dense, h_w8d.data(), h_w8d.size(), hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_scale, h_scale.data(), n_rows * 4, hipMemcpyHostToDevice));
+        const long long total = M * sh->cout;
+        hipLaunchKernelGGL(ref_conv_f8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, d_in8, d_w8dense, d_scale, d_b,
+                           sh->res ? d_res : nullptr, d_ref8, sh->b, sh->h, sh->w, sh->cin, sh->cout);
+        CK(hipDeviceSynchronize());
+        h_ref8.resize(out_elems);
+        CK(hipMemcpy(h_ref8.data(), d_ref8, out_elems * 2, hipMemcpyDeviceToHost));
+    }
 
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -178,12 +246,21 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_dbg, dbg_words * 8));
     CK(hipMemset(d_dbg, 0, dbg_words * 8));
     a.dbg = d_dbg;
+    a.dev_param = getenv("MDHIP_DEV_PARAM") ? atoi(getenv("MDHIP_DEV_PARAM")) : 0;
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     printf("%s: M=%lld N=%d K=%d (%.1f GFLOP)\n", sh->name, M, sh->cout, k_real, flops / 1e9);
+    const ConvArgs a16 = a;
+    ConvArgs af8 = a;
+    af8.in = (const uint16_t*)d_in8; af8.in_f8 = 1; af8.wgt8 = d_w8; af8.scale = d_scale; af8.k_pad8 = k_pad8; af8.groups8 = groups8;
+    af8.C8 = (sh->cin + 15) / 16; af8.wgt4 = nullptr;
     for (int cfg : cfgs) {
+        const bool is_f8 = cfg <= -801 || (cfg >= 0 && !strncmp(conv_cfg(cfg).name, "f8:", 3));
+        if (is_f8 && !want_f8) { printf("  cfg %2d: no fp8 form of this shape\n", cfg); continue; }
+        a = is_f8 ? af8 : a16;
+        const std::vector<uint16_t>& h_ref = is_f8 ? h_ref8 : h_ref16;
         CK(hipMemset(d_out, 0xff, out_elems * 2));
         hipError_t e = conv_launch(cfg, a, 0);
         if (e != hipSuccess) { printf("  cfg %2d launch failed: %s\n", cfg, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
@@ -212,7 +289,7 @@ int main(int argc, char** argv) {
             if (ms < best) best = ms;
         }
         printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
-               cfg <= -401 ? conv6_cfg(conv6_num_cfgs() - 401 - cfg).name : cfg <= -301 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
+               cfg <= -801 ? conv8_cfg(conv8_num_cfgs() - 801 - cfg).name : cfg <= -401 ? conv6_cfg(conv6_num_cfgs() - 401 - cfg).name : cfg <= -301 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
                bad ? "  <-- MISMATCH" : "");
         if (cfg < 0) {
             // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
@@ -220,6 +297,19 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(h.data(), d_dbg, dbg_words * 8, hipMemcpyDeviceToHost));
             double sum[6] = {0, 0, 0, 0, 0, 0}, steps = 0;
             int waves = 0;
+            {   // HW_ID census of the variants that record it (word 7): wave slot / SIMD / CU / SE of every wave
+                int slot_hist[16] = {0}, n = 0, mixed = 0;
+                for (size_t w = 0; w + 4 <= dbg_words / 8; w += 4) {
+                    if (!h[w * 8 + 7]) continue;
+                    for (int k = 0; k < 4; ++k) { ++slot_hist[h[(w + k) * 8 + 7] & 15]; ++n; }
+                    if ((h[w * 8 + 7] & 1) != (h[(w + 3) * 8 + 7] & 1)) ++mixed;
+                }
+                if (n) {
+                    printf("    HW_ID wave-slot histogram over %d waves:", n);
+                    for (int k = 0; k < 16; ++k) if (slot_hist[k]) printf(" [%d]=%d", k, slot_hist[k]);
+                    printf("  (workgroups whose waves disagree on slot parity: %d)\n", mixed);
+                }
+            }
             for (size_t w = 0; w < dbg_words / 8; ++w) {
                 if (!h[w * 8 + 6]) continue;
                 ++waves;
