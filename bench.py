@@ -26,6 +26,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0           # dense MFMA fp8 peak (block-scaled K = 128), same guide
 PEAK_HBM_GBPS = 8000.0             # HBM3E peak (vendor), same guide; measured copy rate 4.75-6.3 TB/s
 GFLOP_PER_IMAGE_1280 = 831.64      # 415.82 GMAC over 163 convs
 # SURVEY.md section 8(d), algorithmic bytes per image at 1280x1280 (NOT the padded figures of the implementation):
@@ -44,8 +45,9 @@ def parse_args():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=1280)
     ap.add_argument('--model', default='YOLOV5X6_MD')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'],
-                    help='storage type of activations and weights (bf16 = the BASELINE.json configuration)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp8'],
+                    help='storage type of activations and weights (bf16 = the BASELINE.json configuration configs[1]; fp8 = '
+                         'configs[4]: bf16 storage with the bottleneck 3x3 convs on e4m3 operands, usually with --batch 64)')
     ap.add_argument('--no-table', action='store_true', help='ignore megadetector_amd/tuned_cfgs.json (heuristic tiles)')
     ap.add_argument('--src', default=None,
                     help='HxW of the source images (e.g. 1536x2048): the real-shape variant of SURVEY.md 8(d), '
@@ -248,6 +250,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.dtype == 'fp8':
+        # static activation scales from the first synthetic batch (mdhip_calibrate), before anything is timed
+        ctx.preprocess(ptr_lists[0] if not args.host_fed else dev_ptrs[0], geoms, Hn, Wn, stream=compute_stream)
+        if args.host_fed:
+            dev_in[0].copy_(host_batches[0])
+            torch.cuda.synchronize()
+            ctx.preprocess(dev_ptrs[0], geoms, Hn, Wn, stream=compute_stream)
+        ctx.calibrate(B, Hn, Wn, stream=compute_stream)
     run(2)                      # initialisation (first-touch of every buffer and code path), not a warm-up step
     run(args.warmup)
     # live roofline measurement: a HIP event pair on the launch stream around the conv stack of every
@@ -311,6 +321,11 @@ def main():
         infos = ctx.op_infos()
         conv = [(o, ms[o['op']]) for o in infos if o['kind'] == 0]
         conv_flops = sum(o['flops'] for o, _ in conv)
+        # the MFMA peak a conv is priced against: 5 PFLOP/s for the launches on e4m3 operands, 2.5 for 16-bit ones;
+        # the stack's peak is the rate at which it would finish with every launch at its own peak
+        op_peak = lambda o: PEAK_FP8_TFLOPS if ctx.conv_cfg_name(o['cfg']).startswith('f8:') else PEAK_BF16_TFLOPS
+        stack_peak = conv_flops / sum(o['flops'] / op_peak(o) for o, _ in conv)
+        f8_share = sum(o['flops'] for o, _ in conv if op_peak(o) == PEAK_FP8_TFLOPS) / conv_flops
         conv_ms = sum(t for _, t in conv)
         other_ms = float(ms.sum() - conv_ms)
         # `achieved`: algorithmic conv FLOPs of one step / duration of the conv-stack launch sequence
@@ -340,8 +355,11 @@ def main():
                 except Exception:
                     pass
         algorithmic_bytes = (ACT_GB_PER_IMAGE * B + WEIGHT_GB) * 1e9 * (Hn * Wn) / (1280.0 * 1280.0)
-        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(stack_peak, 1), 'unit': 'TFLOP/s',
+                'frac': round(achieved / stack_peak, 4),
+                'peak_note': '2500 (dense bf16 MFMA) for 16-bit launches, 5000 (dense fp8 MFMA) for launches on e4m3 operands: '
+                             '{:.1f} % of the FLOPs of this step run on e4m3 operands'.format(100 * f8_share),
+                'traffic': traffic, 'traffic_source': traffic_source,
                 'algorithmic_bytes_per_step': algorithmic_bytes,
                 'traffic_over_algorithmic': None if not traffic else round(traffic / algorithmic_bytes, 3),
                 'kernel': 'conv stack of one step = {} conv launches (conv_igemm_kernel / conv_v2_kernel / conv_v4_kernel / '
@@ -364,7 +382,9 @@ def main():
                 'name': ctx.conv_cfg_name(top[0]), 'launches_per_step': top[1][0],
                 'ms_per_step': round(top[1][1], 3), 'avg_launch_us': round(top[1][1] / top[1][0] * 1e3, 2),
                 'flops_per_step': top[1][2], 'achieved_tflops': round(top[1][2] / (top[1][1] * 1e-3) / 1e12, 2),
-                'frac': round(top[1][2] / (top[1][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                'peak': PEAK_FP8_TFLOPS if ctx.conv_cfg_name(top[0]).startswith('f8:') else PEAK_BF16_TFLOPS,
+                'frac': round(top[1][2] / (top[1][1] * 1e-3) / 1e12 /
+                              (PEAK_FP8_TFLOPS if ctx.conv_cfg_name(top[0]).startswith('f8:') else PEAK_BF16_TFLOPS), 4)}
         # per-stage HBM rooflines (north_star: "rocprof HBM GB/s for preprocess/NMS"): algorithmic bytes of SURVEY.md
         # section 8(d) / duration of the stage's kernels measured live (HIP events on the stream the stage is launched
         # on, timed region; the NMS pair also covers the D2H of the <= 300 x 6 results) -- decode from the per-op events

@@ -35,7 +35,8 @@ extern "C" {
 
 /* arithmetic type of the conv stack */
 #define MDHIP_DTYPE_BF16 0
-#define MDHIP_DTYPE_FP8  1      /* reserved (BASELINE.json configs[4]); not implemented yet */
+#define MDHIP_DTYPE_FP8  1      /* BASELINE.json configs[4]: bf16 storage, the 3x3 convs of the bottlenecks on e4m3
+                                 * operands (W8A8, block-scaled K = 128 MFMA); needs mdhip_calibrate once */
 #define MDHIP_DTYPE_FP16 2      /* fp16 storage of activations and weights (fp32 accumulate): same MFMA rate as
                                  * bf16, 3 more mantissa bits -- the accuracy mode */
 
@@ -124,6 +125,26 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream);
 int mdhip_forward_tta(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream);
 /* anchors per image of the prediction the context currently holds (last forward, augmented forward or mdhip_nms_on) */
 int mdhip_last_num_anchors(mdhip_ctx* ctx);
+
+/* MDHIP_DTYPE_FP8 contexts (BASELINE.json configs[4]; the reference has no reduced precision at all --
+ * pytorch_detector.py:848 hard-wires half_precision = False -- so there is no upstream call this replaces).
+ * Activations and weights stay bf16 in HBM except the hidden tensor of every C3 bottleneck: its 1x1 conv writes it
+ * as OCP e4m3 with one scale per tensor, its 3x3 conv runs on e4m3 operands (weights quantised per output channel at
+ * mdhip_create) with the block-scaled K = 128 MFMA and fp32 accumulation.
+ * mdhip_calibrate runs the batch left by mdhip_preprocess once in bf16, records the largest magnitude of every such
+ * tensor and derives the scales (2x head-room); repeated calls accumulate the ranges.  mdhip_forward fails with
+ * MDHIP_EINVAL until the context has scales (from mdhip_calibrate or mdhip_fp8_set_scales).  Results of an image do
+ * not depend on the batch it travels in; they do depend on the calibration data.
+ * mdhip_fp8_get_scales: returns the number of e4m3 tensors and fills up to max_n entries (any pointer may be NULL):
+ * the scale, the model layer (C3 index) and the op index of the producing 1x1 conv, in execution order.
+ * mdhip_fp8_set_scales: installs scales saved from an earlier calibration (same model, same order). */
+int mdhip_calibrate(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream);
+int mdhip_fp8_num_tensors(mdhip_ctx* ctx);
+int mdhip_fp8_get_scales(mdhip_ctx* ctx, float* scales, int32_t* layers, int32_t* ops, int max_n);
+int mdhip_fp8_set_scales(mdhip_ctx* ctx, const float* scales, int n);
+/* the host-side weight quantiser of the fp8 mode (OCP e4m3, round to nearest even, saturating at +-448); exported so
+ * that the CPU test-suite can pin it against torch.float8_e4m3fn without a GPU */
+int mdhip_f32_to_e4m3(const float* in, uint8_t* out, int n);
 
 /* Replaces nms() (pytorch_detector.py:502-610) on the predictions of the last forward.
  * out: host, [n][max_det][6] = x1,y1,x2,y2,conf,cls in letterboxed pixels, sorted by

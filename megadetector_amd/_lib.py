@@ -64,6 +64,11 @@ SYMBOLS = {
     'mdhip_forward': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     'mdhip_forward_tta': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     'mdhip_last_num_anchors': (C.c_int, [_P]),
+    'mdhip_calibrate': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    'mdhip_fp8_num_tensors': (C.c_int, [_P]),
+    'mdhip_fp8_get_scales': (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
+    'mdhip_fp8_set_scales': (C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
+    'mdhip_f32_to_e4m3': (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_int]),
     'mdhip_nms': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
     'mdhip_nms_enqueue': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _P]),
     'mdhip_nms_wait': (C.c_int, [_P, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_int32))]),

@@ -36,7 +36,7 @@ typedef __attribute__((address_space(3))) char lds_char;
 
 [[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;
 [[maybe_unused]] constexpr int kNumRecords = 0x7fffffff;
-constexpr int kUnitScale = 0x7f7f7f7f;          // E8M0 127 = 2^0 in every byte (tools/probe_fp8.cpp)
+[[maybe_unused]] constexpr int kUnitScale = 0x7f7f7f7f;          // E8M0 127 = 2^0 in every byte (tools/probe_fp8.cpp)
 
 __device__ __forceinline__ float silu_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));

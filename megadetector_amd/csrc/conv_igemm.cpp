@@ -294,6 +294,24 @@ conv_igemm_kernel(const ConvArgs p) {
                     if (m_ok && n < p.N)
                         *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 }
+            } else if (p.out_f8) {
+                // e4m3 output (MDHIP_DTYPE_FP8: the hidden tensor of a bottleneck): 4 channels = 4 bytes per lane and
+                // fragment; the same exchange as the 16-bit path leaves 8 consecutive channels = 8 bytes per lane
+                uint8_t* orow8 = (uint8_t*)p.out + (size_t)m * p.ld_out;
+#pragma unroll
+                for (int j = 0; j + 1 < FN; j += 2) {
+                    const unsigned a0 = pack_e4m3x4(v[j][0], v[j][1], v[j][2], v[j][3], p.out_qscale);
+                    const unsigned b0 = pack_e4m3x4(v[j + 1][0], v[j + 1][1], v[j + 1][2], v[j + 1][3], p.out_qscale);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
+                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
+                    if (m_ok && n < p.N) *(uint2*)(orow8 + n) = make_uint2(t0[0], t0[1]);
+                }
+                if (FN & 1) {
+                    const int j = FN - 1;
+                    const int n = n0 + nl0 + j * 16;
+                    if (m_ok && n < p.N) *(unsigned*)(orow8 + n) = pack_e4m3x4(v[j][0], v[j][1], v[j][2], v[j][3], p.out_qscale);
+                }
             } else {
                 uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
 #pragma unroll

@@ -232,9 +232,10 @@ conv_v2_kernel(const ConvArgs p) {
     // 36k cycles per 160x160 tile, as long as the tile's MFMAs).  Residual rows are fetched one
     // fragment column ahead of their use, so waiting for them never waits for a store.
     const int q4 = lane >> 4;
-    auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t) {
+    auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t, auto out_f8_t) {
         constexpr bool HAS_RES = decltype(has_res_t)::value;
         constexpr bool OUT_F32 = decltype(out_f32_t)::value;
+        constexpr bool OUT_F8 = decltype(out_f8_t)::value;
         const int m0 = tile_m * BM + wm * TM + (lane & 15);
         const int nbase = n0 + wn * TN + q4 * 4;
         // bias of all fragment columns first (scalar loads), then pixel-row by pixel-row so that the
@@ -298,6 +299,24 @@ conv_v2_kernel(const ConvArgs p) {
                     if (m < p.M && n < p.N)
                         *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 }
+            } else if constexpr (OUT_F8) {
+                // e4m3 output (MDHIP_DTYPE_FP8: the hidden tensor of a bottleneck): 4 channels = 4 bytes per lane and
+                // fragment; the same exchange as the 16-bit path leaves 8 consecutive channels = 8 bytes per lane
+                uint8_t* orow8 = (uint8_t*)p.out + (size_t)m * p.ld_out;
+#pragma unroll
+                for (int j = 0; j + 1 < FN; j += 2) {
+                    const unsigned a0 = pack_e4m3x4(v[j][0], v[j][1], v[j][2], v[j][3], p.out_qscale);
+                    const unsigned b0 = pack_e4m3x4(v[j + 1][0], v[j + 1][1], v[j + 1][2], v[j + 1][3], p.out_qscale);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
+                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
+                    if (m < p.M && n < p.N) *(uint2*)(orow8 + n) = make_uint2(t0[0], t0[1]);
+                }
+                if (FN & 1) {
+                    const int j = FN - 1;
+                    const int n = nbase + j * 16;
+                    if (m < p.M && n < p.N) *(unsigned*)(orow8 + n) = pack_e4m3x4(v[j][0], v[j][1], v[j][2], v[j][3], p.out_qscale);
+                }
             } else {
                 // bf16: pairs of fragment columns are exchanged across the four 16-lane rows
                 // (v_permlane32_swap, v_permlane16_swap) so that a lane holds 8 consecutive channels
@@ -328,9 +347,10 @@ conv_v2_kernel(const ConvArgs p) {
     };
     auto epilogue = [&](int tile_m) {
         if constexpr ((PROF & 8) != 0) __builtin_amdgcn_s_setprio(3);
-        if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{});
-        else if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{});
-        else epilogue_t(tile_m, std::false_type{}, std::false_type{});
+        if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{}, std::false_type{});
+        else if (p.out_f8) epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::true_type{});
+        else if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::false_type{});
+        else epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::false_type{});
         if constexpr ((PROF & 8) != 0) __builtin_amdgcn_s_setprio(0);
     };
 

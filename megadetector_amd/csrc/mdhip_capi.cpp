@@ -48,6 +48,12 @@ struct PackedConv {
     size_t w4_off = 0;               // second packing for the row-patch kernel (0 = none)
     int k_pad4 = 0, groups = 0;
     int n_rows = 0, k_pad = 0, cin_pad = 0, kh = 0, kw = 0, c_out = 0, k_real = 0;
+    // fp8 form (MDHIP_DTYPE_FP8, 3x3 / stride-1 bottleneck convs): e4m3 weights [n_rows][groups8*9*128], quantised per
+    // output channel (wscale[n] = max_k |w[n][k]| / 448); scale_off = device array of n_rows floats holding
+    // activation scale x wscale[n], written by mdhip_calibrate / mdhip_fp8_set_scales
+    size_t w8_off = 0, scale_off = 0;
+    int k_pad8 = 0, groups8 = 0;
+    std::vector<float> wscale;
 };
 
 enum OpKind { OP_CONV = 0, OP_POOL = 1, OP_UPSAMPLE = 2, OP_DECODE = 3, OP_COPY = 4 };
@@ -65,6 +71,12 @@ struct Op {
     size_t f32_off = 0;       // decode: logits buffer offset ; conv with out_f32: same
     int f32_ld = 0;
     int forced_cfg = -1;
+    // fp8 mode: this op writes (f8_out) / reads (f8_in) an e4m3 tensor; f8_peer = the op at the other end of it;
+    // act_scale = the tensor's scale (value = e4m3 x act_scale), 0 until calibrated; amax = largest |x| seen
+    bool f8_out = false, f8_in = false;
+    int f8_peer = -1;
+    float act_scale = 0.f, amax = 0.f;
+    size_t amax_off = 0;
     // the configuration chosen for the last (n, h, w): the table walk is not repeated on every launch
     int memo_n = 0, memo_h = 0, memo_w = 0, memo_cfg = -1;
     bool memo_from_table = false;
@@ -111,6 +123,10 @@ struct mdhip_ctx {
     size_t stage_bytes = 0;
     int last_n = 0, last_h = 0, last_w = 0;
     std::string err;
+    // fp8 mode: until every e4m3 tensor has a scale (mdhip_calibrate / mdhip_fp8_set_scales) the forward refuses
+    // to run; `calibrating` makes run_op execute every op in 16 bits and record the range of the tensors
+    bool calibrated = false, calibrating = false;
+    int n_f8 = 0;
     std::vector<hipEvent_t> events;
     std::vector<mdhip_tuned> tuned;   // measured tile choices (tools/autotune.py)
     // optional event pair around every mdhip_forward (bench.py's live roofline measurement)
@@ -161,6 +177,7 @@ struct Planner {
     std::vector<std::vector<uint16_t>> w_host;   // packed weights per PackedConv
     std::vector<std::vector<uint16_t>> w4_host;  // row-patch packing (empty when not applicable)
     std::vector<std::vector<float>> b_host;
+    std::vector<std::vector<uint8_t>> w8_host;   // e4m3 packing (empty when the conv has no fp8 form)
     std::vector<int> layer_c, layer_div;
     std::vector<int> concat_target, concat_choff;   // per producer layer
     std::vector<Tensor> concat_buf;                  // per concat layer
@@ -252,10 +269,30 @@ struct Planner {
                         w4[(size_t)o * pc.k_pad4 + ((ci / 64) * 9 + t) * 64 + (ci % 64)] =
                             w[(size_t)o * pc.k_pad + t * pc.cin_pad + ci];
         }
+        // fp8 mode: 3x3 convs whose input channel count is a multiple of 16 also get the e4m3 packing of
+        // conv_f8.cpp: k = (channel group of 128, tap, channel in group), quantised from the fp32 weights
+        std::vector<uint8_t> w8;
+        if (ctx->dtype == MDHIP_DTYPE_FP8 && !s2d_stem && cs.size() == 1 && pc.kh == 3 && pc.kw == 3 && (c0->c_in % 16) == 0) {
+            pc.groups8 = (c0->c_in + 127) / 128;
+            pc.k_pad8 = pc.groups8 * 9 * 128;
+            pc.wscale.assign(pc.n_rows, 1.0f);
+            w8.assign((size_t)pc.n_rows * pc.k_pad8, 0);
+            for (int o = 0; o < c0->c_out; ++o) {
+                const float* wo = c0->weight + (size_t)o * c0->c_in * 9;
+                float amax = 0.f;
+                for (int k = 0; k < c0->c_in * 9; ++k) amax = std::max(amax, std::fabs(wo[k]));
+                const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+                pc.wscale[o] = sc;
+                for (int ci = 0; ci < c0->c_in; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        w8[(size_t)o * pc.k_pad8 + ((ci / 128) * 9 + t) * 128 + (ci % 128)] = f32_to_e4m3(wo[ci * 9 + t] / sc);
+            }
+        }
         ctx->packed.push_back(pc);
         w_host.push_back(std::move(w));
         w4_host.push_back(std::move(w4));
         b_host.push_back(std::move(b));
+        w8_host.push_back(std::move(w8));
         return (int)ctx->packed.size() - 1;
     }
 
@@ -396,6 +433,15 @@ struct Planner {
                         pc = pack({b2}, false);
                         snprintf(nm, sizeof(nm), "L%d C3.m%d.cv2 3x3", i, j);
                         add_conv(i, nm, T, Y1, pc, 1, 1, true, L.shortcut ? &Y1 : nullptr);
+                        if (ctx->packed[pc].groups8 > 0) {
+                            // fp8 mode: the hidden tensor T of this bottleneck travels as e4m3 (1x1 writes, 3x3 reads)
+                            const int o2 = (int)ctx->ops.size() - 1, o1 = o2 - 1;
+                            ctx->ops[o1].f8_out = true;
+                            ctx->ops[o1].f8_peer = o2;
+                            ctx->ops[o2].f8_in = true;
+                            ctx->ops[o2].f8_peer = o1;
+                            ++ctx->n_f8;
+                        }
                     }
                     pc = pack({&cv[2]}, false);
                     snprintf(nm, sizeof(nm), "L%d C3.cv3 1x1", i);
@@ -526,6 +572,24 @@ int num_anchors_for(const mdhip_ctx* ctx, int h, int w) {
     return a;
 }
 
+int check_calibrated(mdhip_ctx* ctx) {
+    if (ctx->dtype == MDHIP_DTYPE_FP8 && ctx->n_f8 > 0 && !ctx->calibrated)
+        return fail(ctx, MDHIP_EINVAL, "fp8 context without activation scales: call mdhip_calibrate (or mdhip_fp8_set_scales) first");
+    return MDHIP_OK;
+}
+
+// new range -> scale of an e4m3 tensor and the combined per-channel factors of the conv that reads it
+int apply_fp8_scale(mdhip_ctx* ctx, Op& producer, float act_scale) {
+    producer.act_scale = act_scale;
+    Op& consumer = ctx->ops[producer.f8_peer];
+    consumer.act_scale = act_scale;
+    const PackedConv& pc = ctx->packed[consumer.pc];
+    std::vector<float> sc(pc.n_rows, 0.f);
+    for (int n = 0; n < pc.n_rows; ++n) sc[n] = act_scale * pc.wscale[n];
+    HIP_TRY(ctx, hipMemcpy(ctx->warena + pc.scale_off, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+    return MDHIP_OK;
+}
+
 int check_shape(mdhip_ctx* ctx, int n, int h, int w) {
     if (n < 1 || n > ctx->max_batch) return fail(ctx, MDHIP_EINVAL, "batch %d outside [1,%d]", n, ctx->max_batch);
     if (h < ctx->max_stride || w < ctx->max_stride || h % ctx->max_stride || w % ctx->max_stride)
@@ -576,6 +640,24 @@ int choose_cfg(int M, int n_rows) {
     return best;
 }
 
+// tile choice without a table entry: the fill-aware heuristic over the first-generation configurations for a 16-bit
+// op; for an op with an e4m3 operand, the best-filling configuration among those that take it
+int choose_cfg_for(mdhip_ctx* ctx, const ConvArgs& a) {
+    if (!a.in_f8 && !a.out_f8) return choose_cfg(a.M, a.n_rows);
+    int best = -1;
+    float best_score = -1.f;
+    for (int i = 0; i < conv_num_cfgs(); ++i) {
+        if (!conv_api(ctx).supports(i, a)) continue;
+        const ConvCfg& c = conv_cfg(i);
+        const int tn = (a.n_rows + c.bn - 1) / c.bn, tm = (a.M + c.bm - 1) / c.bm;
+        const float useful = ((float)a.n_rows / (tn * c.bn)) * ((float)a.M / ((float)tm * c.bm));
+        const float fill = std::min(1.0f, (float)tm * tn / (256.0f * c.blocks_per_cu));
+        const float score = useful * (0.35f + 0.65f * fill) * (c.blocks_per_cu == 2 ? 1.0f : 0.95f);
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    return best < 0 ? 0 : best;
+}
+
 void fill_conv_args(mdhip_ctx* ctx, Op& op, int n, int h, int w, ConvArgs& a) {
     const PackedConv& pc = ctx->packed[op.pc];
     const int H = h / op.in.div, W = w / op.in.div;
@@ -621,6 +703,21 @@ void fill_conv_args(mdhip_ctx* ctx, Op& op, int n, int h, int w, ConvArgs& a) {
     a.wgt4 = pc.w4_off ? (const uint16_t*)(ctx->warena + pc.w4_off) : nullptr;
     a.k_pad4 = pc.k_pad4;
     a.groups = pc.groups;
+    if (ctx->dtype == MDHIP_DTYPE_FP8 && !ctx->calibrating) {
+        if (op.f8_in) {
+            // the e4m3 tensor lives in the 16-bit tensor's allocation: same pixel pitch, counted in bytes
+            a.in_f8 = 1;
+            a.wgt8 = (const uint8_t*)(ctx->warena + pc.w8_off);
+            a.scale = (const float*)(ctx->warena + pc.scale_off);
+            a.k_pad8 = pc.k_pad8;
+            a.groups8 = pc.groups8;
+            a.C8 = (op.in.c + 15) / 16;
+        }
+        if (op.f8_out) {
+            a.out_f8 = 1;
+            a.out_qscale = 1.0f / op.act_scale;
+        }
+    }
     op.gm = a.M;
     op.gn = pc.c_out;
     op.gk = pc.k_real;
@@ -693,11 +790,11 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
                     }                                   // else: heuristic below (bitwise family)
                 }
             }
-            if (cfg < 0) cfg = choose_cfg(a.M, a.n_rows);
+            if (cfg < 0) cfg = choose_cfg_for(ctx, a);
             hipError_t le = conv_api(ctx).launch(cfg, a, s);
             if (le == hipErrorInvalidValue && from_table) {      // table entry from another build: not applicable
                 (void)hipGetLastError();
-                cfg = choose_cfg(a.M, a.n_rows);
+                cfg = choose_cfg_for(ctx, a);
                 from_table = false;
                 le = conv_api(ctx).launch(cfg, a, s);
             }
@@ -706,6 +803,9 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
                 op.memo_n = n; op.memo_h = h; op.memo_w = w; op.memo_cfg = cfg; op.memo_from_table = from_table;
             }
             HIP_TRY(ctx, le);
+            if (ctx->calibrating && op.f8_out)
+                HIP_TRY(ctx, launch_absmax_view((const uint16_t*)(ctx->arena + op.out.off), op.out.ld, op.out.c, (long long)a.M,
+                                                0, (float*)(ctx->arena + op.amax_off), s));
             break;
         }
         case OP_POOL: {
@@ -755,7 +855,7 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
 // =========================================================================================
 extern "C" {
 
-const char* mdhip_version(void) { return "mdhip 0.1 (gfx950, bf16)"; }
+const char* mdhip_version(void) { return "mdhip 0.2 (gfx950: bf16 / fp16 storage, fp8 bottlenecks)"; }
 
 const char* mdhip_last_error(mdhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -765,8 +865,8 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     *out = nullptr;
     if (!model || !model->layers || !model->convs || model->n_layers < 1)
         return fail(nullptr, MDHIP_EINVAL, "empty model description");
-    if (dtype != MDHIP_DTYPE_BF16 && dtype != MDHIP_DTYPE_FP16)
-        return fail(nullptr, MDHIP_EUNSUPPORTED, "dtype %d not implemented (bf16 and fp16 storage only)", dtype);
+    if (dtype != MDHIP_DTYPE_BF16 && dtype != MDHIP_DTYPE_FP16 && dtype != MDHIP_DTYPE_FP8)
+        return fail(nullptr, MDHIP_EUNSUPPORTED, "dtype %d not implemented (bf16, fp16, fp8)", dtype);
     if (max_batch < 1 || max_h < 64 || max_w < 64) return fail(nullptr, MDHIP_EINVAL, "bad capacity %d x %dx%d", max_batch, max_h, max_w);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -833,6 +933,12 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     ctx->nms_out_off = P.alloc_bytes((size_t)max_batch * kNmsMaxDet * 6 * 4);
     ctx->nms_cnt_off = P.alloc_bytes((size_t)max_batch * 4);
     ctx->geom_off = P.alloc_bytes((size_t)max_batch * sizeof(LetterboxDev));
+    {   // fp8 calibration: one range word per e4m3 tensor
+        const size_t base = P.alloc_bytes((size_t)std::max(1, ctx->n_f8) * 4);
+        size_t k = 0;
+        for (Op& op : ctx->ops)
+            if (op.f8_out) op.amax_off = base + 4 * k++;
+    }
     ctx->arena_bytes = P.cursor + 256;
 
     // weight arena
@@ -849,6 +955,12 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
         if (!P.w4_host[i].empty()) {
             ctx->packed[i].w4_off = wcur;
             wcur = align_up(wcur + P.w4_host[i].size() * 2, 256);
+        }
+        if (!P.w8_host[i].empty()) {
+            ctx->packed[i].w8_off = wcur;
+            wcur = align_up(wcur + P.w8_host[i].size(), 256);
+            ctx->packed[i].scale_off = wcur;
+            wcur = align_up(wcur + (size_t)ctx->packed[i].n_rows * 4, 256);
         }
     }
     ctx->warena_bytes = wcur;
@@ -881,6 +993,10 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
         CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].b_off, P.b_host[i].data(), P.b_host[i].size() * 4, hipMemcpyHostToDevice));
         if (!P.w4_host[i].empty())
             CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].w4_off, P.w4_host[i].data(), P.w4_host[i].size() * 2, hipMemcpyHostToDevice));
+        if (!P.w8_host[i].empty()) {
+            CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].w8_off, P.w8_host[i].data(), P.w8_host[i].size(), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemset(ctx->warena + ctx->packed[i].scale_off, 0, (size_t)ctx->packed[i].n_rows * 4));
+        }
     }
     ctx->nms_scr.keys[0] = (uint32_t*)(ctx->arena + nms_kv[0]);
     ctx->nms_scr.keys[1] = (uint32_t*)(ctx->arena + nms_kv[1]);
@@ -982,6 +1098,7 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
 int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     if (!ctx) return MDHIP_EINVAL;
     if (int rc = check_shape(ctx, n, h, w)) return rc;
+    if (int rc = check_calibrated(ctx)) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int slot = (int)(ctx->fwd_count % mdhip_ctx::kFwdRing);
@@ -1012,6 +1129,7 @@ int mdhip_forward_tta(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     if (int rc = check_shape(ctx, n, h, w)) return rc;
     if (ctx->last_n < n || ctx->last_h != h || ctx->last_w != w)
         return fail(ctx, MDHIP_EINVAL, "mdhip_forward_tta needs mdhip_preprocess of the same batch first");
+    if (int rc = check_calibrated(ctx)) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const float scales[3] = {1.0f, 0.83f, 0.67f};
@@ -1064,6 +1182,90 @@ int mdhip_forward_tta(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     return MDHIP_OK;
 }
 
+// fp8 mode (BASELINE.json configs[4]).  The reference has no reduced precision (pytorch_detector.py:848
+// half_precision = False), so there is nothing upstream to mirror: post-training static quantisation of the hidden
+// tensor of every bottleneck, per-tensor activation scale from the largest magnitude seen on the calibration batches
+// (x FP8_RANGE_MARGIN head-room), per-output-channel weight scales fixed at mdhip_create.
+static constexpr float kFp8RangeMargin = 2.0f;
+
+int mdhip_calibrate(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
+    if (!ctx) return MDHIP_EINVAL;
+    if (ctx->dtype != MDHIP_DTYPE_FP8) return fail(ctx, MDHIP_EINVAL, "mdhip_calibrate: not an fp8 context");
+    if (int rc = check_shape(ctx, n, h, w)) return rc;
+    if (ctx->last_n < n || ctx->last_h != h || ctx->last_w != w)
+        return fail(ctx, MDHIP_EINVAL, "mdhip_calibrate needs mdhip_preprocess of the same batch first");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (Op& op : ctx->ops)
+        if (op.f8_out) HIP_TRY(ctx, hipMemsetAsync(ctx->arena + op.amax_off, 0, 4, s));
+    // one forward in 16 bits (every op, the 3x3 convs through their bf16 weights), ranges recorded on the way
+    ctx->calibrating = true;
+    for (Op& op : ctx->ops) op.memo_cfg = -1;
+    ctx->cur_tta = DecodeTta();
+    ctx->cur_A = num_anchors_for(ctx, h, w);
+    int rc = MDHIP_OK;
+    for (Op& op : ctx->ops)
+        if ((rc = run_op(ctx, op, n, h, w, s)) != MDHIP_OK) break;
+    ctx->calibrating = false;
+    for (Op& op : ctx->ops) op.memo_cfg = -1;
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (Op& op : ctx->ops) {
+        if (!op.f8_out) continue;
+        float m = 0.f;
+        HIP_TRY(ctx, hipMemcpy(&m, ctx->arena + op.amax_off, 4, hipMemcpyDeviceToHost));
+        if (!(m == m) || m > 3.0e38f) return fail(ctx, MDHIP_EINVAL, "calibration saw a non-finite activation in %s", op.name.c_str());
+        op.amax = std::max(op.amax, m);                                   // ranges accumulate over calibration calls
+        const float scale = std::max(op.amax, 1e-20f) * kFp8RangeMargin / 448.0f;
+        if (int r2 = apply_fp8_scale(ctx, op, scale)) return r2;
+    }
+    ctx->calibrated = true;
+    ctx->last_A = ctx->cur_A;
+    return MDHIP_OK;
+}
+
+int mdhip_fp8_num_tensors(mdhip_ctx* ctx) { return ctx ? ctx->n_f8 : MDHIP_EINVAL; }
+
+int mdhip_f32_to_e4m3(const float* in, uint8_t* out, int n) {
+    if (!in || !out || n < 0) return MDHIP_EINVAL;
+    for (int i = 0; i < n; ++i) out[i] = f32_to_e4m3(in[i]);
+    return MDHIP_OK;
+}
+
+int mdhip_fp8_get_scales(mdhip_ctx* ctx, float* scales, int32_t* layers, int32_t* ops, int max_n) {
+    if (!ctx || max_n < 0) return MDHIP_EINVAL;
+    int k = 0;
+    for (size_t i = 0; i < ctx->ops.size(); ++i) {
+        const Op& op = ctx->ops[i];
+        if (!op.f8_out) continue;
+        if (k < max_n) {
+            if (scales) scales[k] = op.act_scale;
+            if (layers) layers[k] = op.layer;
+            if (ops) ops[k] = (int32_t)i;
+        }
+        ++k;
+    }
+    return k;
+}
+
+int mdhip_fp8_set_scales(mdhip_ctx* ctx, const float* scales, int n) {
+    if (!ctx || !scales) return MDHIP_EINVAL;
+    if (ctx->dtype != MDHIP_DTYPE_FP8) return fail(ctx, MDHIP_EINVAL, "mdhip_fp8_set_scales: not an fp8 context");
+    if (n != ctx->n_f8) return fail(ctx, MDHIP_EINVAL, "%d scales for %d fp8 tensors", n, ctx->n_f8);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int k = 0;
+    for (Op& op : ctx->ops) {
+        if (!op.f8_out) continue;
+        const float sc = scales[k++];
+        if (!(sc > 0.f) || sc > 3.0e38f) return fail(ctx, MDHIP_EINVAL, "scale %d is not a positive finite number", k - 1);
+        op.amax = sc * 448.0f / kFp8RangeMargin;
+        if (int rc = apply_fp8_scale(ctx, op, sc)) return rc;
+    }
+    ctx->calibrated = true;
+    for (Op& op : ctx->ops) op.memo_cfg = -1;
+    return MDHIP_OK;
+}
+
 int mdhip_last_num_anchors(mdhip_ctx* ctx) { return ctx ? ctx->last_A : 0; }
 
 int mdhip_time_forwards(mdhip_ctx* ctx, int enable) {
@@ -1093,6 +1295,7 @@ int mdhip_forward_times(mdhip_ctx* ctx, float* ms, int max_n) {
 int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hip_stream) {
     if (!ctx || !ms) return MDHIP_EINVAL;
     if (int rc = check_shape(ctx, n, h, w)) return rc;
+    if (int rc = check_calibrated(ctx)) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t need = ctx->ops.size() + 1;
@@ -1121,6 +1324,7 @@ int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hi
 int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float* ms_avg, void* hip_stream) {
     if (!ctx || !ms_avg || op < 0 || op >= (int)ctx->ops.size() || iters < 1) return MDHIP_EINVAL;
     if (int rc = check_shape(ctx, n, h, w)) return rc;
+    if (int rc = check_calibrated(ctx)) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     while (ctx->events.size() < 2) {

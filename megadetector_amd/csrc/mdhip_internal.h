@@ -110,6 +110,16 @@ __device__ __forceinline__ uint32_t st_pack2(float a, float b) {
 }
 __device__ __forceinline__ float st_unpack(uint16_t h) { return bf16_to_f32(h); }
 #endif
+// four fp32 values -> four e4m3 bytes (RNE, saturating at +-448): the out_f8 epilogue of the 16-bit kernels
+__device__ __forceinline__ uint32_t pack_e4m3x4(float a, float b, float c, float d, float qscale) {
+    a = __builtin_fminf(__builtin_fmaxf(a * qscale, -448.0f), 448.0f);
+    b = __builtin_fminf(__builtin_fmaxf(b * qscale, -448.0f), 448.0f);
+    c = __builtin_fminf(__builtin_fmaxf(c * qscale, -448.0f), 448.0f);
+    d = __builtin_fminf(__builtin_fmaxf(d * qscale, -448.0f), 448.0f);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (uint32_t)r;
+}
 // a fragment that is not read from LDS (ablation variants of the kernels only)
 __device__ __forceinline__ frag8_t frag_dummy(int v) {
     frag8_t z;
@@ -234,6 +244,8 @@ hipError_t launch_upsample2x(const uint16_t* in, int ld_in, uint16_t* out, int l
 // strided channel-slice copy
 hipError_t launch_copy_view(const uint16_t* in, int ld_in, uint16_t* out, int ld_out, int c,
                             long long pixels, hipStream_t s);
+// max |x| of a 16-bit view, atomically max-ed into *out (a non-negative float, zero it first)
+hipError_t launch_absmax_view(const uint16_t* in, int ld, int c, long long pixels, int f16, float* out, hipStream_t s);
 // Detect decode of one level: logits fp32 [n*ny*nx][ld] -> pred[n][n_anchors][no].  A test-time-augmentation
 // pass keeps anchors [keep_from, keep_to) of its own numbering, de-scales / un-flips the boxes and writes them
 // at out_off of the concatenated prediction; the default is the plain forward.

@@ -4,6 +4,8 @@
 // Compiled with -ffp-contract=off: the fixed-point bilinear coordinates and the Detect
 // decode must round exactly like the un-fused NumPy / PyTorch expressions they replace.
 
+#include <algorithm>
+
 #include "mdhip_internal.h"
 
 namespace mdhip {
@@ -273,6 +275,36 @@ hipError_t launch_copy_view(const uint16_t* in, int ld_in, uint16_t* out, int ld
     const long long total = pixels * (c / 8);
     hipLaunchKernelGGL(copy_view_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        in, ld_in, out, ld_out, c / 8, pixels);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// max |x| over a 16-bit view (fp8 calibration: the range of a bottleneck's hidden tensor)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+absmax_view_kernel(const uint16_t* __restrict__ in, int ld, int c8, long long pixels, int f16, unsigned* __restrict__ out) {
+    const long long total = pixels * c8;
+    float m = 0.f;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long pix = t / c8;
+        const int ch = (int)(t - pix * c8);
+        const uint4 v = *(const uint4*)(in + (size_t)pix * ld + ch * 8);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m = fmaxf(m, fabsf(st_to_f32((uint16_t)(w[k] & 0xffff), f16)));
+            m = fmaxf(m, fabsf(st_to_f32((uint16_t)(w[k] >> 16), f16)));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(out, __float_as_uint(m));      // non-negative floats order as integers
+}
+
+hipError_t launch_absmax_view(const uint16_t* in, int ld, int c, long long pixels, int f16, float* out, hipStream_t s) {
+    const long long total = pixels * (c / 8);
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(absmax_view_kernel, dim3(blocks), dim3(256), 0, s, in, ld, c / 8, pixels, f16, (unsigned*)out);
     return hipGetLastError();
 }
 

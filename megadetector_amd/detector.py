@@ -75,7 +75,10 @@ class HIPDetector:
         |d conf| against the fp32 evaluation the reference performs stays below the reference's own bar between
         environments (0.005-0.01, md_tests.py:96-100,1779) with an 8x margin on every model measured
         (profiles/r2a_accuracy_x6.txt); 'bf16' is the throughput configuration BASELINE.json names (3 % faster,
-        8 significant bits).
+        8 significant bits); 'fp8' is BASELINE.json configs[4]: bf16 storage, the bottleneck 3x3 convs on e4m3 operands;
+        its static activation scales come from `fp8_scales` (a list saved from an earlier run, HipContext.fp8_scales)
+        or, without it, from the FIRST batch this detector processes (mdhip_calibrate) -- results then depend on that
+        batch; a stated-tolerance throughput mode, not a reference-grade one (tests/test_gpu_fp8.py).
         """
         opts = dict(detector_options or {})
         self.use_model_native_classes = parse_bool_string(opts.get('use_model_native_classes', False))
@@ -137,6 +140,12 @@ class HIPDetector:
         self._ctx = HipContext(weights, device=_device_ordinal(device), dtype=opts.get('dtype') or DEFAULT_DTYPE,
                                max_batch=self.max_batch, max_h=max_size, max_w=max_size)
         self.model = self._ctx
+        self._fp8_pending = False
+        if self._ctx.dtype == 'fp8':
+            if opts.get('fp8_scales'):
+                self._ctx.set_fp8_scales([float(v) for v in opts['fp8_scales']])
+            else:
+                self._fp8_pending = True
 
     # -----------------------------------------------------------------------------------
     def preprocess_image(self, img_original, image_id='unknown', image_size=None, verbose=False):
@@ -284,6 +293,9 @@ class HIPDetector:
         n = len(group_items)
         ctx = self._ctx
         ctx.preprocess(images, geoms, h, w)
+        if self._fp8_pending:               # fp8 mode without saved scales: this batch calibrates them
+            ctx.calibrate(n, h, w)
+            self._fp8_pending = False
         if augment:
             ctx.forward_tta(n, h, w)        # yolov5 _forward_augment: 3 passes, concatenated predictions
         else:
@@ -346,6 +358,9 @@ class HIPDetector:
             base = stage.data_ptr()
             ctx = self._ctx
             ctx.preprocess([base + off for off in offs], geoms, h, w, stream=comp.cuda_stream)
+            if self._fp8_pending:
+                ctx.calibrate(n, h, w, stream=comp.cuda_stream)
+                self._fp8_pending = False
             ev = torch.cuda.Event()
             ev.record(comp)
             pl['consumed'][k] = ev

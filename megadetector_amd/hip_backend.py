@@ -168,6 +168,26 @@ class HipContext:
     def last_num_anchors(self):
         return self.lib.mdhip_last_num_anchors(self.h)
 
+    # -- fp8 mode (dtype='fp8') -----------------------------------------------------------
+    def calibrate(self, n, h, w, stream=0):
+        """records the ranges of the e4m3 tensors on the batch left by preprocess() and derives their scales"""
+        self._check(self.lib.mdhip_calibrate(self.h, int(n), int(h), int(w), C.c_void_p(stream)), 'mdhip_calibrate')
+
+    def fp8_scales(self):
+        """[(scale, model layer, op index)] of the e4m3 tensors, in execution order"""
+        n = self.lib.mdhip_fp8_num_tensors(self.h)
+        if n <= 0:
+            return []
+        sc = (C.c_float * n)()
+        ly = (C.c_int32 * n)()
+        op = (C.c_int32 * n)()
+        self.lib.mdhip_fp8_get_scales(self.h, sc, ly, op, n)
+        return [(float(sc[i]), int(ly[i]), int(op[i])) for i in range(n)]
+
+    def set_fp8_scales(self, scales):
+        arr = (C.c_float * len(scales))(*[float(v) for v in scales])
+        self._check(self.lib.mdhip_fp8_set_scales(self.h, arr, len(scales)), 'mdhip_fp8_set_scales')
+
     def nms(self, n, conf_thres, iou_thres, max_det=300, stream=0):
         out = np.empty((n, max_det, 6), dtype=np.float32)
         counts = np.empty((n,), dtype=np.int32)

@@ -129,16 +129,28 @@ class Forward:
                          residual adds and SiLU are evaluated in fp32 before rounding,
                          exactly as the fused HIP epilogue does.
     emulate_bf16='fp16': the same with fp16 storage (the HIP path's MDHIP_DTYPE_FP16 mode).
+    emulate_bf16='fp8' : the MDHIP_DTYPE_FP8 mode (no upstream counterpart: the reference runs fp32 only,
+                         pytorch_detector.py:848): bf16 storage as above, and in every C3 bottleneck whose hidden width
+                         is a multiple of 16 the hidden tensor is quantised to OCP e4m3 with the per-tensor scale
+                         fp8_scales[(layer, j)] (value = e4m3 x scale; the 1x1 conv's SiLU output times 1/scale,
+                         clamped to +-448, rounded to nearest even, no bf16 rounding in between) and the 3x3 conv
+                         runs on e4m3 weights quantised per output channel (scale = max|w| / 448 of the fp32 folded
+                         weights), fp32 accumulation, accumulator x (tensor scale x channel scale) + bias.
     """
 
-    def __init__(self, yaml, weights, emulate_bf16=False, keep=None):
+    def __init__(self, yaml, weights, emulate_bf16=False, keep=None, fp8_scales=None):
         self.yaml = yaml
         self.layers = parse_model(yaml)
         self.emulate = bool(emulate_bf16)
         self._round = _fp16_round if emulate_bf16 == 'fp16' else _bf16_round
+        self.fp8 = emulate_bf16 == 'fp8'
+        self.fp8_scales = dict(fp8_scales or {})
         self.w = {}
+        self.w32 = {}
         for k, v in weights.items():
             v = v.detach().to(torch.float32)
+            if self.fp8 and k.endswith('.weight'):
+                self.w32[k] = v
             if emulate_bf16 and k.endswith('.weight'):
                 v = self._round(v)
             self.w[k] = v
@@ -160,11 +172,30 @@ class Forward:
             y = self._round(y)
         return y
 
+    def _bottleneck_fp8(self, y1, pre, j, scale, shortcut):
+        """one bottleneck with its hidden tensor and 3x3 weights in e4m3 (see the class docstring)"""
+        n1, n2 = '{}.m.{}.cv1.conv'.format(pre, j), '{}.m.{}.cv2.conv'.format(pre, j)
+        t = F.silu(F.conv2d(y1, self.w[n1 + '.weight'], self.w[n1 + '.bias']))
+        s_t = torch.tensor(scale, dtype=torch.float32)
+        q = (t * (torch.tensor(1.0, dtype=torch.float32) / s_t)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+        w = self.w32[n2 + '.weight']
+        amax = w.abs().amax(dim=(1, 2, 3))
+        s_w = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        wq = (w / s_w.view(-1, 1, 1, 1)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+        acc = F.conv2d(q, wq, None, stride=1, padding=1)
+        y = F.silu(acc * (s_t * s_w).view(1, -1, 1, 1) + self.w[n2 + '.bias'].view(1, -1, 1, 1))
+        if shortcut:
+            y = y1 + y
+        return self._round(y)
+
     def _c3(self, x, L):
         pre = 'model.{}'.format(L['i'])
         y1 = self._conv(x, pre + '.cv1.conv', 1, 1, 0)
         y2 = self._conv(x, pre + '.cv2.conv', 1, 1, 0)
         for j in range(L['n']):
+            if self.fp8 and (L['i'], j) in self.fp8_scales:
+                y1 = self._bottleneck_fp8(y1, pre, j, self.fp8_scales[(L['i'], j)], L['shortcut'])
+                continue
             t = self._conv(y1, '{}.m.{}.cv1.conv'.format(pre, j), 1, 1, 0)
             y1 = self._conv(t, '{}.m.{}.cv2.conv'.format(pre, j), 3, 1, 1,
                             residual=y1 if L['shortcut'] else None)

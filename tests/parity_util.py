@@ -41,8 +41,18 @@ def oracle_input(images, image_size, stride):
     return O.to_batch_tensor([i['img_processed'] for i in infos]), infos
 
 
-def oracle_forward(weights, x, emulate_bf16, keep=None, augment=False):
-    fw = Y.Forward(weights.yaml, weights.torch_state(), emulate_bf16=emulate_bf16, keep=keep)
+def fp8_scale_map(ctx):
+    """{(model layer, bottleneck index): scale} of an fp8 HipContext, for the oracle's emulate_bf16='fp8' mode"""
+    out, seen = {}, {}
+    for scale, layer, _op in ctx.fp8_scales():
+        j = seen.get(layer, 0)
+        seen[layer] = j + 1
+        out[(layer, j)] = scale
+    return out
+
+
+def oracle_forward(weights, x, emulate_bf16, keep=None, augment=False, fp8_scales=None):
+    fw = Y.Forward(weights.yaml, weights.torch_state(), emulate_bf16=emulate_bf16, keep=keep, fp8_scales=fp8_scales)
     with torch.no_grad():
         return (fw.forward_augment(x) if augment else fw(x)), fw
 

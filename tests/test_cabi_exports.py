@@ -106,3 +106,30 @@ def test_detector_input_validation_without_gpu():
         det.generate_detections_one_batch([img, info], ['a', 'b'])
     with pytest.raises(RuntimeError, match='preprocess_only'):
         det.generate_detections_one_batch([img], ['a'])
+
+
+def test_host_e4m3_quantiser_matches_torch():
+    """fp8 mode: the library quantises the 3x3 weights on the host (mdhip_capi.cpp pack(), mdhip_internal.h
+    f32_to_e4m3); the oracle uses torch.float8_e4m3fn after a clamp to +-448.  Every e4m3 value, every midpoint
+    between neighbours (ties to even), the subnormal range, saturation, signs, and random values must agree."""
+    import ctypes as C
+    import torch
+    from megadetector_amd import _lib
+    lib = _lib.load()
+    grid = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).to(torch.float32)
+    grid = grid[torch.isfinite(grid)]
+    pos = torch.sort(grid[grid >= 0]).values
+    mids = (pos[:-1] + pos[1:]) / 2
+    g = torch.Generator().manual_seed(5)
+    rnd = torch.cat([torch.randn(20000, generator=g) * s for s in (1e-3, 0.02, 1.0, 30.0, 400.0)])
+    x = torch.cat([grid, mids, -mids, torch.nextafter(mids, mids * 2), torch.nextafter(mids, mids * 0),
+                   torch.tensor([0.0, -0.0, 448.0, 449.0, 464.0, 480.0, 1e9, -1e9, 2.0 ** -10, 2.0 ** -11, 1e-30, float('inf')]),
+                   rnd]).to(torch.float32).contiguous()
+    out = np.empty(x.numel(), dtype=np.uint8)
+    xin = x.numpy()
+    assert lib.mdhip_f32_to_e4m3(xin.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_uint8)), x.numel()) == 0
+    want = x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    # -0.0 and +0.0 results may differ in the sign bit for inputs that round to zero; values must be equal
+    got_f = torch.from_numpy(out).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    want_f = torch.from_numpy(want).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    np.testing.assert_array_equal(got_f, want_f)

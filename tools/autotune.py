@@ -30,7 +30,7 @@ def main():
     ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'tuned_cfgs.json'))
     ap.add_argument('--table', default=None)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp8'])
     ap.add_argument('--family-from', default=None,
                     help='existing table (measured at the canonical batch size): only configurations of the same kernel '
                          'family (same fp32 summation order) as its entry for the layer are tried, so that an '
@@ -57,6 +57,8 @@ def main():
         ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
     x = torch.randint(0, 256, (B, HH, WW, 3), dtype=torch.uint8, device='cuda')
     ctx.preprocess([int(x[i].data_ptr()) for i in range(B)], [(HH, WW, HH, WW, 0, 0)] * B, HH, WW)
+    if args.dtype == 'fp8':
+        ctx.calibrate(B, HH, WW)
     ctx.forward(B, HH, WW)                     # real activations in every buffer
     infos = ctx.op_infos()
     ncfg = ctx.num_conv_cfgs()
