@@ -43,7 +43,8 @@ __device__ __forceinline__ float silu_f32(float x) {
 }
 
 constexpr int f8_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
-constexpr int f8_lds_bytes(int bm, int bn) { return 2 * f8_run_pieces(bm) * 1024 + 2 * bn * 128 + 1024; }
+// 2 run buffers + 2 weight stages + 2 KiB: the row of zeros, the staged bias and the staged scales
+constexpr int f8_lds_bytes(int bm, int bn) { return 2 * f8_run_pieces(bm) * 1024 + 2 * bn * 128 + 2048; }
 constexpr int f8_blocks_per_cu(int bm, int bn, int nw) {
     int b = 163840 / f8_lds_bytes(bm, bn);
     if (b > 32 / nw) b = 32 / nw;
@@ -112,7 +113,16 @@ conv_f8_kernel(const ConvArgs p) {
     const int steps_per_tile = 9 * G;
     const int total_runs = my_tiles * runs_per_tile;
 
-    if (tid < 64) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+    // the row of zeros; behind it the bias (offset 256) and the per-channel scales (offset 256 + 4 BN) of this
+    // workgroup's BN output channels, staged once and read by every tile's epilogue with ds_read_b128
+    static_assert(BN * 8 + 256 <= 2048, "bias / scale staging area");
+    constexpr int BIAS_OFF = ZERO_OFF + 256, SCALE_OFF = BIAS_OFF + BN * 4;
+    if (tid < 16) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+    for (int c = tid; c < BN; c += NW * 64) {
+        const bool ok = n0 + c < p.n_rows;
+        *(__attribute__((address_space(3))) float*)(smem + BIAS_OFF + c * 4) = ok ? p.bias[n0 + c] : 0.f;
+        *(__attribute__((address_space(3))) float*)(smem + SCALE_OFF + c * 4) = ok ? p.scale[n0 + c] : 0.f;
+    }
 
     // ---- weight stream: slab (cg, tap) = 128 bytes of every row at byte offset step * 128 ---------
     const int lr = lane >> 3;
@@ -229,36 +239,14 @@ conv_f8_kernel(const ConvArgs p) {
 
     // ---- epilogue (conv_v5.cpp's, plus the per-channel scale) -----------------------------------------------
     const int q4 = lane >> 4;
-    auto sload16 = [&](const float* ptr) -> f32x16 {
-        f32x16 r;
-        const unsigned long long a = (unsigned long long)ptr;
-        const unsigned long long s =
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((int)a);
-        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(s) : "memory");
-        return r;
-    };
-    auto pick4 = [&](const f32x16& b16) -> f32x4 {
-        const f32x4 g0 = {b16[0], b16[1], b16[2], b16[3]}, g1 = {b16[4], b16[5], b16[6], b16[7]},
-                    g2 = {b16[8], b16[9], b16[10], b16[11]}, g3 = {b16[12], b16[13], b16[14], b16[15]};
-        return q4 == 0 ? g0 : (q4 == 1 ? g1 : (q4 == 2 ? g2 : g3));
-    };
     auto epilogue_t = [&](int tile_m, auto has_res_t) __attribute__((always_inline)) {
         constexpr bool HAS_RES = decltype(has_res_t)::value;
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // MFMA (16 passes) write -> VALU read of the accumulators
         const int m0 = tile_m * BM + wm * TM + (lane & 15);
         const int nbase = n0 + wn * TN + q4 * 4;
-        f32x4 bv[FN], sv[FN];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int nb = n0 + wn * TN + j * 16;                // wave-uniform
-            bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            sv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (nb < p.n_rows) {
-                bv[j] = pick4(sload16(p.bias + nb));
-                sv[j] = pick4(sload16(p.scale + nb));
-            }
-        }
+        // bias and scale are re-read from LDS for every pixel row (volatile: 40 live registers less than keeping them
+        // across the rows, which made the kernel spill)
+        auto ld4 = [&](int off) -> f32x4 { return *(const volatile __attribute__((address_space(3))) f32x4*)(smem + off); };
         uint2 rrow[2][FN];
         auto fetch_res_row = [&](int i, uint2 (&r)[FN]) {
             const int m = min(m0 + i * 16, p.M - 1);
@@ -275,9 +263,11 @@ conv_f8_kernel(const ConvArgs p) {
             float v[FN][4];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
+                const int cl = (wn * TN + j * 16 + q4 * 4) * 4;
+                const f32x4 svj = ld4(SCALE_OFF + cl), bvj = ld4(BIAS_OFF + cl);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][r] * sv[j][r] + bv[j][r];
+                    float t = acc[i][j][r] * svj[r] + bvj[r];
                     if ((PROF & 4) == 0 && p.act) t = silu_f32(t);
                     v[j][r] = t;
                 }

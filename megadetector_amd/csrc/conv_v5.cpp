@@ -109,8 +109,13 @@ conv_v5_kernel(const ConvArgs p) {
     const int steps_per_tile = 9 * G;
     const int total_runs = my_tiles * runs_per_tile;
 
-    // the row of zeros that invalid (pixel, tap) pairs read
-    if (tid < 64) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+    // the row of zeros that invalid (pixel, tap) pairs read; behind it (offset 256 of the same KiB) the bias of this
+    // workgroup's BN output channels, staged once: the epilogue of every tile reads its 4 channels per fragment column
+    // with one ds_read_b128 instead of a scalar load + wait per column (5 dependent round trips per tile)
+    static_assert(BN * 4 + 256 <= 1024, "bias staging area");
+    if (tid < 16) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+    for (int c = tid; c < BN; c += NW * 64)
+        *(__attribute__((address_space(3))) float*)(smem + ZERO_OFF + 256 + c * 4) = (n0 + c < p.n_rows) ? p.bias[n0 + c] : 0.f;
 
     // ---- weight stream: slab (cg, tap) = 128 bytes of every row at byte offset step * 128 ---------
     const int lr = lane >> 3;
@@ -231,34 +236,31 @@ conv_v5_kernel(const ConvArgs p) {
         float bv[FN][4];
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int nb = n0 + wn * TN + j * 16;                // wave-uniform: bias comes through s_load
-            bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
-            if (nb < p.n_rows) {
-                f32x16 b16;
-                const unsigned long long ba = (unsigned long long)(p.bias + nb);
-                const unsigned long long bs =
-                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) |
-                    (unsigned)__builtin_amdgcn_readfirstlane((int)ba);
-                asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b16) : "s"(bs) : "memory");
-                const f32x4 g0 = {b16[0], b16[1], b16[2], b16[3]}, g1 = {b16[4], b16[5], b16[6], b16[7]},
-                            g2 = {b16[8], b16[9], b16[10], b16[11]}, g3 = {b16[12], b16[13], b16[14], b16[15]};
-                const f32x4 g = q4 == 0 ? g0 : (q4 == 1 ? g1 : (q4 == 2 ? g2 : g3));
-                bv[j][0] = g[0]; bv[j][1] = g[1]; bv[j][2] = g[2]; bv[j][3] = g[3];
-            }
+            const f32x4 g = *(const __attribute__((address_space(3))) f32x4*)(smem + ZERO_OFF + 256 + (wn * TN + j * 16 + q4 * 4) * 4);
+            bv[j][0] = g[0]; bv[j][1] = g[1]; bv[j][2] = g[2]; bv[j][3] = g[3];
         }
-        uint2 rrow[2][FN];
-        auto fetch_res_row = [&](int i, uint2 (&r)[FN]) {
+        // The residual is read the way the output is written: 16 bytes per lane = 8 consecutive channels of a pair of
+        // fragment columns (64 contiguous bytes per pixel and instruction, 3 loads per pixel row instead of 5), and
+        // brought back to the accumulator layout by the inverse of the store exchange (v_permlane16_swap, then
+        // v_permlane32_swap: both are involutions).
+        constexpr int NPAIR = FN / 2;
+        uint4 rpair[2][NPAIR > 0 ? NPAIR : 1];
+        uint2 rlast[2];
+        auto fetch_res_row = [&](int i, uint4 (&rp)[NPAIR > 0 ? NPAIR : 1], uint2& rl) {
             // branch-free (clamped) addresses: a load under a divergent branch would make the compiler
             // fall back from counted vmcnt waits to vmcnt(0), which also waits for stores
             const int m = min(m0 + i * 16, p.M - 1);
+            const uint16_t* rrow_p = p.res + (size_t)m * p.ld_res;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) r[j] = *(const uint2*)(p.res + (size_t)m * p.ld_res + min(nbase + j * 16, p.N - 4));
+            for (int jp = 0; jp < NPAIR; ++jp)
+                rp[jp] = *(const uint4*)(rrow_p + min(n0 + wn * TN + jp * 32 + q4 * 8, p.N - 8));
+            if (FN & 1) rl = *(const uint2*)(rrow_p + min(nbase + (FN - 1) * 16, p.N - 4));
         };
-        if constexpr (HAS_RES) fetch_res_row(0, rrow[0]);
+        if constexpr (HAS_RES) fetch_res_row(0, rpair[0], rlast[0]);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             if constexpr (HAS_RES) {
-                if (i + 1 < FM) fetch_res_row(i + 1, rrow[(i + 1) & 1]);
+                if (i + 1 < FM) fetch_res_row(i + 1, rpair[(i + 1) & 1], rlast[(i + 1) & 1]);
             }
             const int m = m0 + i * 16;
             float v[FN][4];
@@ -271,13 +273,25 @@ conv_v5_kernel(const ConvArgs p) {
                     v[j][r] = t;
                 }
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (HAS_RES) {
-                    const uint2 rv = rrow[i & 1][j];
-                    v[j][0] += st_unpack((uint16_t)(rv.x & 0xffff));
-                    v[j][1] += st_unpack((uint16_t)(rv.x >> 16));
-                    v[j][2] += st_unpack((uint16_t)(rv.y & 0xffff));
-                    v[j][3] += st_unpack((uint16_t)(rv.y >> 16));
+            }
+            if constexpr (HAS_RES) {
+                auto add4 = [&](int j, unsigned lo, unsigned hi) {
+                    v[j][0] += st_unpack((uint16_t)(lo & 0xffff));
+                    v[j][1] += st_unpack((uint16_t)(lo >> 16));
+                    v[j][2] += st_unpack((uint16_t)(hi & 0xffff));
+                    v[j][3] += st_unpack((uint16_t)(hi >> 16));
+                };
+#pragma unroll
+                for (int jp = 0; jp < NPAIR; ++jp) {
+                    const uint4 d = rpair[i & 1][jp];            // as stored: (t0[0], t1[0], t0[1], t1[1])
+                    auto s0 = __builtin_amdgcn_permlane16_swap(d.x, d.z, false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(d.y, d.w, false, false);
+                    auto a0 = __builtin_amdgcn_permlane32_swap(s0[0], s0[1], false, false);     // (a0, b0)
+                    auto a1 = __builtin_amdgcn_permlane32_swap(s1[0], s1[1], false, false);     // (a1, b1)
+                    add4(2 * jp, a0[0], a1[0]);
+                    add4(2 * jp + 1, a0[1], a1[1]);
                 }
+                if (FN & 1) add4(FN - 1, rlast[i & 1].x, rlast[i & 1].y);
             }
             if constexpr ((PROF & 2) != 0) {
 #pragma unroll
