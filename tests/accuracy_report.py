@@ -46,9 +46,11 @@ def main():
     for label, W in cases:
         p32, _ = PU.oracle_forward(W, x, emulate_bf16=False)
         p32 = p32.numpy()
-        for dtype in ('bf16', 'fp16'):
+        for dtype in ('bf16', 'fp16', 'fp8'):
             ctx = HipContext(W, device=0, dtype=dtype, max_batch=2, max_h=hh, max_w=ww)
             ctx.preprocess(imgs, [(hh, ww, hh, ww, 0, 0)] * 2, hh, ww)
+            if dtype == 'fp8':
+                ctx.calibrate(2, hh, ww)          # (calibrated on the evaluation batch itself: the best case)
             ctx.forward(2, hh, ww)
             got = ctx.read_predictions(2, hh, ww)
             ctx.close()
