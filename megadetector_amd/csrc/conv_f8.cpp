@@ -47,8 +47,7 @@ constexpr int f8_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
 constexpr int f8_lds_bytes(int bm, int bn) { return 2 * f8_run_pieces(bm) * 1024 + 2 * bn * 128 + 2048; }
 constexpr int f8_blocks_per_cu(int bm, int bn, int nw) {
     int b = 163840 / f8_lds_bytes(bm, bn);
-    if (b > 32 / nw) b = 32 / nw;
-    if (b > 2) b = 2;
+    if (b > 8 / nw) b = 8 / nw;          // two waves per SIMD (256 registers each)
     return b < 1 ? 1 : b;
 }
 constexpr int f8_waves_per_simd(int bm, int bn, int nw) {
@@ -462,10 +461,12 @@ conv_f8_kernel(const ConvArgs p) {
     X(0, 128, 160, 2, 2, 0) \
     X(1, 192, 80, 4, 1, 0)  \
     X(2, 256, 160, 4, 2, 0) \
-    X(3, 128, 80, 4, 1, 0)
+    X(3, 128, 80, 4, 1, 0)  \
+    X(4, 64, 160, 2, 2, 0)  \
+    X(5, 64, 80, 2, 1, 0)
 #define MDHIP_CONV8_PROF(X) \
-    X(4, 128, 160, 2, 2, 1)  \
-    X(5, 128, 160, 2, 2, 16)
+    X(6, 128, 160, 2, 2, 1)  \
+    X(7, 128, 160, 2, 2, 16)
 
 static const ConvCfg g_cfgs8[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \

@@ -54,8 +54,7 @@ constexpr int v5_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
 constexpr int v5_lds_bytes(int bm, int bn) { return 2 * v5_run_pieces(bm) * 1024 + 2 * bn * 128 + 1024; }
 constexpr int v5_blocks_per_cu(int bm, int bn, int nw) {
     int b = 163840 / v5_lds_bytes(bm, bn);
-    if (b > 32 / nw) b = 32 / nw;
-    if (b > 2) b = 2;
+    if (b > 8 / nw) b = 8 / nw;          // two waves per SIMD (256 registers each)
     return b < 1 ? 1 : b;
 }
 constexpr int v5_waves_per_simd(int bm, int bn, int nw) {
@@ -476,11 +475,13 @@ conv_v5_kernel(const ConvArgs p) {
     X(0, 128, 160, 2, 2, 0) \
     X(1, 128, 80, 4, 1, 0)  \
     X(2, 256, 160, 4, 2, 0) \
-    X(3, 192, 80, 4, 1, 0)
+    X(3, 192, 80, 4, 1, 0)  \
+    X(4, 64, 160, 2, 2, 0)  \
+    X(5, 64, 80, 2, 1, 0)
 #define MDHIP_CONV5_PROF(X)  \
-    X(4, 128, 160, 2, 2, 1)  \
-    X(5, 128, 160, 2, 2, 16) \
-    X(6, 128, 160, 2, 2, 22)
+    X(6, 128, 160, 2, 2, 1)  \
+    X(7, 128, 160, 2, 2, 16) \
+    X(8, 128, 160, 2, 2, 22)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
