@@ -62,6 +62,9 @@ def parse_args():
                     help='only warm-up + timed steps (no per-stage / per-op extras): for rocprofv3 runs')
     ap.add_argument('--cpu-seconds', type=float, default=14.0)
     ap.add_argument('--no-cpu-single-thread', action='store_true', help='skip the one-thread CPU row (one image, ~1 min)')
+    ap.add_argument('--nms-own-stream', action='store_true',
+                    help='NMS + D2H of step i on their own stream next to the forward of step i+1 (round 1); default: on the '
+                         'compute stream behind the forward')
     ap.add_argument('--profile-out', default=None, help='write per-op timings (json) here')
     return ap.parse_args()
 
@@ -194,15 +197,17 @@ def main():
         if nms_done[(i - 2) % 4] is not None:
             comp_s.wait_event(nms_done[(i - 2) % 4])      # the prediction buffer this forward overwrites has been consumed
         ctx.forward(B, Hn, Wn, stream=compute_stream)
-        fwd_done[k].record(comp_s)
-        nms_s.wait_event(fwd_done[k])
+        ns = nms_s if args.nms_own_stream else comp_s
+        if args.nms_own_stream:
+            fwd_done[k].record(comp_s)
+            nms_s.wait_event(fwd_done[k])
         if stage_live['on']:
-            ev_nms[i % RING][0].record(nms_s)
-        ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=k, stream=nms_s.cuda_stream)
+            ev_nms[i % RING][0].record(ns)
+        ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=k, stream=ns.cuda_stream)
         if stage_live['on']:
-            ev_nms[i % RING][1].record(nms_s)
+            ev_nms[i % RING][1].record(ns)
         ev = torch.cuda.Event()
-        ev.record(nms_s)
+        ev.record(ns)
         nms_done[k] = ev
 
     def enqueue(i):

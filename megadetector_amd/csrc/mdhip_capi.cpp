@@ -930,6 +930,7 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     ctx->pred_off = ctx->pred_offs[0];
     size_t nms_kv[4];
     for (int i = 0; i < 4; ++i) nms_kv[i] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * 4);
+    const size_t nms_seg = P.alloc_bytes((size_t)max_batch * kNmsScanParts * 4);
     ctx->nms_out_off = P.alloc_bytes((size_t)max_batch * kNmsMaxDet * 6 * 4);
     ctx->nms_cnt_off = P.alloc_bytes((size_t)max_batch * 4);
     ctx->geom_off = P.alloc_bytes((size_t)max_batch * sizeof(LetterboxDev));
@@ -1003,6 +1004,7 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     ctx->nms_scr.vals[0] = (uint32_t*)(ctx->arena + nms_kv[2]);
     ctx->nms_scr.vals[1] = (uint32_t*)(ctx->arena + nms_kv[3]);
     ctx->nms_scr.cap = ctx->a_cap;
+    ctx->nms_scr.seg_cnt = (uint32_t*)(ctx->arena + nms_seg);
     CREATE_TRY(hipDeviceSynchronize());
 #undef CREATE_TRY
     *out = ctx;

@@ -269,10 +269,12 @@ hipError_t launch_s2d_to_nchw_f32(const uint16_t* in, float* out, int n, int h, 
 // ---------------------------------------------------------------------------------------
 // NMS (nms_kernels.cpp)
 // ---------------------------------------------------------------------------------------
+constexpr int kNmsScanParts = 16;   // workgroups per image of the candidate scan (nms_kernels.cpp stage A)
 struct NmsScratch {
     uint32_t* keys[2];     // [n][cap] each
     uint32_t* vals[2];
     int cap;               // candidates capacity per image (= max anchors)
+    uint32_t* seg_cnt;     // [n][kNmsScanParts] candidates found by each scan workgroup
 };
 hipError_t launch_nms(const float* pred, int n, int n_anchors, int no, float conf_thres,
                       float iou_thres, int max_det, const NmsScratch& scr, float* out /*device [n][max_det][6]*/,

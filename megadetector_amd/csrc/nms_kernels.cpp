@@ -13,8 +13,14 @@
 // the survivors are emitted in rank order.  All comparisons and the IoU use the same fp32
 // operations as the reference (division included); compiled with -ffp-contract=off.
 //
-// Stages inside the workgroup (NT = 1024 threads, image = blockIdx.x):
-//   A. compaction in anchor order (ballot + popcount scans)    -> keys/vals buffer 0
+// Stage A (round 2) is its own launch spread over the chip: one CU reads 3.26 MB per image at ~15 GB/s through
+// 100 barrier-separated iterations -- 0.4 of the 0.6 ms the whole NMS took at batch 32.  kScanParts workgroups per
+// image compact contiguous anchor ranges into their own segment of buffer 0 (anchor order inside a segment, segments
+// in anchor order: the same candidate order as before); the per-image workgroup then gathers the segments.
+//
+// Stages (NT = 1024 threads, image = blockIdx.x):
+//   A. nms_scan_kernel: compaction in anchor order (ballot + popcount scans) -> segments of keys/vals buffer 0
+//   A'. gather of the segments into buffer 1
 //   B. 4 x 8-bit stable LSD radix sort (descending confidence): every wavefront owns a
 //      contiguous segment and a private 256-bin histogram in LDS; ranks inside a 64-key tile
 //      come from an 8-ballot match-any
@@ -66,28 +72,27 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
     return ovr > thr;
 }
 
-__global__ void __launch_bounds__(NT)
-nms_image_kernel(const float* __restrict__ pred_all, int n_anchors, int no, float conf_thres,
-                 float iou_thres, int max_det, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1,
-                 uint32_t* vals1, int cap, float* __restrict__ out, int* __restrict__ counts) {
-    __shared__ NmsLds L;
-    const int img = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+// stage A: workgroup (part, image) compacts anchors [part * per_part, (part + 1) * per_part) into keys0 / vals0 at
+// offset part * per_part of the image's buffer, and stores the number of candidates it found
+constexpr int NTS = 256;
+__global__ void __launch_bounds__(NTS)
+nms_scan_kernel(const float* __restrict__ pred_all, int n_anchors, int no, float conf_thres, int per_part,
+                uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0, int cap, uint32_t* __restrict__ seg_cnt) {
+    __shared__ uint32_t wave_cnt[NTS / 64];
+    const int img = blockIdx.y, part = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pred = pred_all + (size_t)img * n_anchors * no;
-    uint32_t* kbuf[2] = {keys0 + (size_t)img * cap, keys1 + (size_t)img * cap};
-    uint32_t* vbuf[2] = {vals0 + (size_t)img * cap, vals1 + (size_t)img * cap};
+    uint32_t* kb = keys0 + (size_t)img * cap + (size_t)part * per_part;
+    uint32_t* vb = vals0 + (size_t)img * cap + (size_t)part * per_part;
     const int nc = no - 5;
     const unsigned long long lt = lanemask_lt(lane);
-
-    // ---------------- stage A: compaction (anchor order preserved) ----------------------
+    const int a_lo = part * per_part, a_hi = min(a_lo + per_part, n_anchors);
     int count = 0;
-    for (int base = 0; base < n_anchors; base += NT) {
+    for (int base = a_lo; base < a_hi; base += NTS) {
         const int a = base + tid;
         bool pass = false;
         uint32_t key = 0, val = 0;
-        if (a < n_anchors) {
+        if (a < a_hi) {
             const float* p = pred + (size_t)a * no;
             const float obj = p[4];
             if (obj > conf_thres) {
@@ -105,21 +110,59 @@ nms_image_kernel(const float* __restrict__ pred_all, int n_anchors, int no, floa
             }
         }
         const unsigned long long bal = __ballot(pass);
-        if (lane == 0) L.wave_cnt[wave] = (uint32_t)__popcll(bal);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t off = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) {
-            const uint32_t c = L.wave_cnt[w];
+        for (int w = 0; w < NTS / 64; ++w) {
+            const uint32_t c = wave_cnt[w];
             if (w < wave) off += c;
             tot += c;
         }
         if (pass) {
             const int pos = count + (int)off + __popcll(bal & lt);
-            kbuf[0][pos] = key;
-            vbuf[0][pos] = val;
+            kb[pos] = key;
+            vb[pos] = val;
         }
         count += (int)tot;
+        __syncthreads();
+    }
+    if (tid == 0) seg_cnt[(size_t)img * kNmsScanParts + part] = (uint32_t)count;
+}
+
+__global__ void __launch_bounds__(NT)
+nms_image_kernel(const float* __restrict__ pred_all, int n_anchors, int no, float conf_thres,
+                 float iou_thres, int max_det, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1,
+                 uint32_t* vals1, int cap, int per_part, const uint32_t* __restrict__ seg_cnt,
+                 float* __restrict__ out, int* __restrict__ counts) {
+    __shared__ NmsLds L;
+    const int img = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const float* pred = pred_all + (size_t)img * n_anchors * no;
+    uint32_t* kbuf[2] = {keys0 + (size_t)img * cap, keys1 + (size_t)img * cap};
+    uint32_t* vbuf[2] = {vals0 + (size_t)img * cap, vals1 + (size_t)img * cap};
+    const unsigned long long lt = lanemask_lt(lane);
+
+    // ---------------- stage A': gather the scan kernel's segments (anchor order preserved) -> buffer 1 ---------
+    int count = 0;
+    {
+        uint32_t seg_off[kNmsScanParts + 1];
+        seg_off[0] = 0;
+#pragma unroll
+        for (int q = 0; q < kNmsScanParts; ++q) seg_off[q + 1] = seg_off[q] + seg_cnt[(size_t)img * kNmsScanParts + q];
+        count = (int)seg_off[kNmsScanParts];
+#pragma unroll
+        for (int q = 0; q < kNmsScanParts; ++q) {
+            const int c = (int)(seg_off[q + 1] - seg_off[q]);
+            const uint32_t* sk = kbuf[0] + (size_t)q * per_part;
+            const uint32_t* sv = vbuf[0] + (size_t)q * per_part;
+            for (int t = tid; t < c; t += NT) {
+                kbuf[1][seg_off[q] + t] = sk[t];
+                vbuf[1][seg_off[q] + t] = sv[t];
+            }
+        }
         __syncthreads();
     }
 
@@ -129,10 +172,10 @@ nms_image_kernel(const float* __restrict__ pred_all, int n_anchors, int no, floa
         const int lo = min(wave * seg, count), hi = min(lo + seg, count);
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = pass * 8;
-            const uint32_t* sk = kbuf[pass & 1];
-            const uint32_t* sv = vbuf[pass & 1];
-            uint32_t* dk = kbuf[(pass & 1) ^ 1];
-            uint32_t* dv = vbuf[(pass & 1) ^ 1];
+            const uint32_t* sk = kbuf[(pass & 1) ^ 1];       // the gathered candidates start in buffer 1
+            const uint32_t* sv = vbuf[(pass & 1) ^ 1];
+            uint32_t* dk = kbuf[pass & 1];
+            uint32_t* dv = vbuf[pass & 1];
             for (int i = tid; i < NWV * 256; i += NT) (&L.u.hist[0][0])[i] = 0;
             __syncthreads();
             for (int i = lo + lane; i < hi; i += 64)
@@ -194,7 +237,7 @@ nms_image_kernel(const float* __restrict__ pred_all, int n_anchors, int no, floa
             __syncthreads();
         }
     }
-    const uint32_t* sorted_v = vbuf[0];
+    const uint32_t* sorted_v = vbuf[1];              // four passes: back in buffer 1 (also when count <= 1)
 
     // ---------------- stage C: greedy suppression over sorted candidates ----------------
     int nk = 0;
@@ -278,10 +321,15 @@ nms_image_kernel(const float* __restrict__ pred_all, int n_anchors, int no, floa
 hipError_t launch_nms(const float* pred, int n, int n_anchors, int no, float conf_thres,
                       float iou_thres, int max_det, const NmsScratch& scr, float* out, int* counts,
                       hipStream_t s) {
-    if (n_anchors > scr.cap || max_det > kNmsMaxDet || max_det < 1) return hipErrorInvalidValue;
+    if (n_anchors > scr.cap || max_det > kNmsMaxDet || max_det < 1 || !scr.seg_cnt) return hipErrorInvalidValue;
+    const int per_part = (n_anchors + kNmsScanParts - 1) / kNmsScanParts;
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(kNmsScanParts, n), dim3(NTS), 0, s, pred, n_anchors, no, conf_thres, per_part,
+                       scr.keys[0], scr.vals[0], scr.cap, scr.seg_cnt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nms_image_kernel, dim3(n), dim3(NT), 0, s, pred, n_anchors, no, conf_thres,
                        iou_thres, max_det, scr.keys[0], scr.vals[0], scr.keys[1], scr.vals[1],
-                       scr.cap, out, counts);
+                       scr.cap, per_part, scr.seg_cnt, out, counts);
     return hipGetLastError();
 }
 

@@ -364,18 +364,13 @@ class HIPDetector:
             ev = torch.cuda.Event()
             ev.record(comp)
             pl['consumed'][k] = ev
-            # NMS + D2H on their own stream, next to the following batch's forward (two prediction buffers in the
-            # library): behind this forward, and this forward behind the NMS that read the buffer it overwrites
-            prev = pl['nms_done'][(nms_slot - 2) % 4]
-            if prev is not None:
-                comp.wait_event(prev)
+            # NMS + D2H behind the forward on the compute stream.  (Round 1 ran them on their own stream next to the
+            # following batch's forward; measured in round 2: the 1024-thread NMS workgroups keep the persistent conv
+            # workgroups off their CUs, the forward slows by more than the NMS costs in line: 37.6 vs 37.2 ms / step.)
             ctx.forward(n, h, w, stream=comp.cuda_stream)
-            fwd_ev = torch.cuda.Event()
-            fwd_ev.record(comp)
-            pl['nms_s'].wait_event(fwd_ev)
-            ctx.nms_enqueue(n, detection_threshold, self._nms_iou(), 300, slot=nms_slot, stream=pl['nms_s'].cuda_stream)
+            ctx.nms_enqueue(n, detection_threshold, self._nms_iou(), 300, slot=nms_slot, stream=comp.cuda_stream)
             done = torch.cuda.Event()
-            done.record(pl['nms_s'])
+            done.record(comp)
             pl['nms_done'][nms_slot] = done
         return {'items': group_items, 'h': h, 'w': w, 'slot': nms_slot, 'copied': pl['copied'][k], 'images': images}
 
