@@ -481,7 +481,7 @@ const Family g_fams[] = {
     {conv2_num_cfgs, conv2_cfg, conv2_supports_l, conv2_launch, conv2_init, true, -1, false, true},
     {conv4_num_cfgs, conv4_cfg, conv4_supports, conv4_launch, conv4_init, false, -201, false, false},
     {conv5_num_cfgs, conv5_cfg, conv5_supports, conv5_launch, conv5_init, false, -301, false, false},
-    {conv6_num_cfgs, conv6_cfg, conv6_supports, conv6_launch, conv6_init, false, -401, false, false},
+    {conv6_num_cfgs, conv6_cfg, conv6_supports, conv6_launch, conv6_init, true, -401, false, false},     // the stem kernel: same K order
     {conv8_num_cfgs, conv8_cfg, conv8_supports, conv8_launch, conv8_init, false, -801, true, false},
 };
 constexpr int kNumFams = (int)(sizeof(g_fams) / sizeof(g_fams[0]));

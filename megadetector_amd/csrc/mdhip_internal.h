@@ -179,7 +179,7 @@ struct ConvCfg {
 //   conv2_* : second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
 //   conv4_* : row-patch direct convolution for 3x3 / stride 1 (conv_v4.cpp)
 //   conv5_* : 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp)
-//   conv6_* : the same reuse with 32x32x16 MFMA fragments and one 8-wave workgroup per CU (conv_v6.cpp)
+//   conv6_* : the stem (3x3 over 16-channel space-to-depth pixels, N = 80) with its weights in registers (conv_v6.cpp)
 //   conv8_* : conv_v5's structure on e4m3 operands with the block-scaled K = 128 MFMA (conv_f8.cpp)
 // conv_launch returns hipSuccess or the launch error; conv_init raises the dynamic-LDS limits (one-off);
 // conv_cfg_is_bitwise_family is false for kernels whose result equals the others' up to fp32 summation

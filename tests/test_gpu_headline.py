@@ -173,3 +173,31 @@ def test_headline_configuration_one_full_size_image_through_the_detector():
     print('1280x1280: box {:.2e}/{:.2e}, conf {:.2e}, {} detections'.format(e_box[0], e_box[1], e_conf, len(res['detections'])))
     # measured: box 3.1e-2 / 3.9e-4, conf 6.2e-2 (bf16, Detect gain 22, 102000 anchors): E2E_CONF_TOL_FP32_ORACLE's regime
     assert e_box[0] < 5e-2 and e_box[1] < LAYER_MEAN_TOL and e_conf < 8e-2
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_stem_kernel_is_bit_identical_to_the_implicit_gemm(dtype):
+    """conv_v6.cpp (the stem with its weights in registers, one image-row segment per tile): same K order and k-step
+    order as conv_igemm.cpp -> the same bits, on row widths that are and are not multiples of its 128-pixel tile, at
+    image borders, and for several images per batch."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    for (n, hh, ww) in ((2, 640, 640), (3, 384, 640), (1, 1280, 1280), (2, 256, 192)):
+        ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+        try:
+            stem = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith('stem:')]
+            assert len(stem) == 1 and ctx.cfg_is_bitwise(stem[0])
+            gemm = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == '128x80/4x1/s3/p0'][0]
+            imgs = PU.random_images(n, hh, ww, seed=hh + ww)
+            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            ctx.set_op_cfg(0, gemm)
+            ctx.forward(n, hh, ww)
+            ref = ctx.read_layer(0, n).copy()
+            assert ctx.op_supports_cfg(0, stem[0])
+            ctx.set_op_cfg(0, stem[0])
+            ctx.forward(n, hh, ww)
+            assert ctx.conv_cfg_name(ctx.op_infos()[0]['cfg']).startswith('stem:')
+            np.testing.assert_array_equal(ctx.read_layer(0, n), ref)
+        finally:
+            ctx.close()

@@ -244,7 +244,9 @@ def test_tile_configurations_agree_bitwise(n6):
                 else:
                     ctx.set_op_cfg(op, -1)
             if switched == 0:
-                assert not ctx.cfg_is_bitwise(cfg), cfg      # only the row-patch kernel may find nothing here
+                # only the row-patch / row-segment / e4m3 kernels and the dedicated stem kernel (x6 stem only:
+                # tests/test_gpu_headline.py) may find nothing in this network
+                assert not ctx.cfg_is_bitwise(cfg) or ctx.conv_cfg_name(cfg).startswith('stem:'), cfg
                 continue
             ctx.forward(2, 192, 256)
             got = ctx.read_predictions(2, 192, 256)
