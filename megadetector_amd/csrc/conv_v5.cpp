@@ -492,11 +492,19 @@ static const ConvCfg g_cfgs5[] = {
 };
 constexpr int kNumProf5 = 3;
 
-int conv5_num_cfgs() { return (int)(sizeof(g_cfgs5) / sizeof(g_cfgs5[0])) - kNumProf5; }
-const ConvCfg& conv5_cfg(int i) { return g_cfgs5[i]; }
+// ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp (same K order, same
+// results), then the developer variants
+constexpr int kNumMain5 = (int)(sizeof(g_cfgs5) / sizeof(g_cfgs5[0])) - kNumProf5;
+
+int conv5_num_cfgs() { return kNumMain5 + conv5s_num_cfgs(); }
+const ConvCfg& conv5_cfg(int i) {
+    if (i < kNumMain5) return g_cfgs5[i];
+    if (i < conv5_num_cfgs()) return conv5s_cfg(i - kNumMain5);
+    return g_cfgs5[i - conv5s_num_cfgs()];
+}
 
 hipError_t conv5_init() {
-    hipError_t e = hipSuccess;
+    hipError_t e = conv5s_init();
 #define X(id, bm, bn, wm, wn, prof)                                                              \
     if (e == hipSuccess)                                                                       \
         e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof>,                \
@@ -508,13 +516,17 @@ hipError_t conv5_init() {
 
 bool conv5_supports(int cfg, const ConvArgs& a) {
     if (cfg < 0 || cfg >= conv5_num_cfgs() + kNumProf5) return false;
-    return a.wgt4 != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H &&
-           a.Wo == a.W && a.C8 >= 8 && (a.N % 8) == 0 &&
-           (long long)(2 * a.W + g_cfgs5[cfg].bm + 16) * a.ld_in * 2 + 4096 < 0x7fffffffLL;
+    const bool ok = a.wgt4 != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H &&
+                    a.Wo == a.W && a.C8 >= 8 && (a.N % 8) == 0 &&
+                    (long long)(2 * a.W + conv5_cfg(cfg).bm + 16) * a.ld_in * 2 + 4096 < 0x7fffffffLL;
+    if (ok && cfg >= kNumMain5 && cfg < conv5_num_cfgs()) return conv5s_supports(cfg - kNumMain5, a);
+    return ok;
 }
 
 hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     if (!conv5_supports(cfg, a)) return hipErrorInvalidValue;
+    if (cfg >= kNumMain5 && cfg < conv5_num_cfgs()) return conv5s_launch(cfg - kNumMain5, a, s);
+    if (cfg >= conv5_num_cfgs()) cfg -= conv5s_num_cfgs();        // developer variants
     const ConvCfg& c = g_cfgs5[cfg];
     ConvArgs p = a;
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;

@@ -178,7 +178,8 @@ struct ConvCfg {
 //             kernel (every shape), then conv_v2.cpp's, conv_v4.cpp's, conv_v5.cpp's, conv_v6.cpp's
 //   conv2_* : second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
 //   conv4_* : row-patch direct convolution for 3x3 / stride 1 (conv_v4.cpp)
-//   conv5_* : 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp)
+//   conv5_* : 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp); its configurations
+//             for small launches (conv5s_*, conv_v5s.cpp) are listed behind its own
 //   conv6_* : the stem (3x3 over 16-channel space-to-depth pixels, N = 80) with its weights in registers (conv_v6.cpp)
 //   conv8_* : conv_v5's structure on e4m3 operands with the block-scaled K = 128 MFMA (conv_f8.cpp)
 // conv_launch returns hipSuccess or the launch error; conv_init raises the dynamic-LDS limits (one-off);
@@ -207,6 +208,11 @@ struct ConvCfg {
     bool conv5_supports(int cfg, const ConvArgs& a); \
     hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s); \
     hipError_t conv5_init(); \
+    int conv5s_num_cfgs(); \
+    const ConvCfg& conv5s_cfg(int i); \
+    bool conv5s_supports(int cfg, const ConvArgs& a); \
+    hipError_t conv5s_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv5s_init(); \
     int conv6_num_cfgs(); \
     const ConvCfg& conv6_cfg(int i); \
     bool conv6_supports(int cfg, const ConvArgs& a); \

@@ -113,6 +113,8 @@ int main(int argc, char** argv) {
     for (const Shape& s : kShapes)
         if (!strcmp(s.name, argv[1])) sh = &s;
     if (!sh) { fprintf(stderr, "unknown shape %s\n", argv[1]); return 2; }
+    Shape sh_b;                                                   // CONVBENCH_B=<n>: the same layer at another batch
+    if (const char* eb = getenv("CONVBENCH_B")) { sh_b = *sh; sh_b.b = atoi(eb); sh = &sh_b; }
     const int iters = atoi(argv[2]);
     std::vector<int> cfgs;
     for (int i = 3; i < argc; ++i) {
