@@ -13,7 +13,9 @@ Pinned (tests/test_oracle_*.py) against the golden vectors the reference tree ho
   * megadetector/utils/ct_utils.py:1332-1346,:1467-1493            -> truncate/round/yolo->xywh/IoU
 PARITY UNPINNED: cv2.resize bit-exactness (OpenCV is not installed here and the reference
 holds no resize fixtures); the fixed-point bilinear below follows OpenCV's imgproc/resize.cpp
-(HResizeLinear / VResizeLinear<uchar,int,short>, INTER_RESIZE_COEF_BITS=11).
+(HResizeLinear / VResizeLinear<uchar,int,short>, INTER_RESIZE_COEF_BITS=11).  Second source (not a pin):
+tests/test_oracle_resize_second_source.py holds both resize restatements against torch's float bilinear
+interpolation / block means (within one grey level everywhere).
 """
 
 import math

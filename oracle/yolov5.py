@@ -278,7 +278,8 @@ class Forward:
         F.interpolate(align_corners=False) to (int(h*s), int(w*s)), padded right/bottom with 0.447 to a
         multiple of the largest stride; boxes divided by the scale, x un-flipped against the original
         width; the last (A//g) anchors of the first pass and the first (A//g)*4^(nl-1) anchors of the last
-        pass dropped, g = sum(4^l); concatenation along the anchor axis.  Parity unpinned (no yolov5 here).
+        pass dropped, g = sum(4^l); concatenation along the anchor axis.  Parity unpinned (no yolov5 here);
+        second source: tests/test_oracle_tta_second_source.py (package-style restatement around an nn.Module).
         """
         import math
         det = self.layers[-1]
