@@ -6,6 +6,7 @@ reference's shape (process_video.py:211-258).
 """
 
 import json
+import os
 
 import numpy as np
 import pytest
@@ -100,3 +101,79 @@ def test_opencv_source_fails_loudly_without_cv2(tmp_path):
         pass
     with pytest.raises(RuntimeError, match='opencv'):
         PV.OpenCVFrameSource(str(p))
+
+
+class _StandInCv2:
+    """the part of cv2's call protocol OpenCVFrameSource uses (video_utils.py:130-195,:377-440): VideoCapture(path)
+    .read() -> (ok, BGR frame), .get(CAP_PROP_*), .release(); cvtColor(image, COLOR_BGR2RGB).  Frames come from an .npy
+    file; `short_by` makes the stream end before the frame count the container reports (truncated files do that)."""
+    CAP_PROP_FRAME_COUNT, CAP_PROP_FPS, COLOR_BGR2RGB = 7, 5, 4
+    released = 0
+
+    class VideoCapture:
+        def __init__(self, path):
+            d = np.load(path, allow_pickle=True).item() if os.path.getsize(path) > 8 else None
+            self.frames = [] if d is None else list(d['bgr'])
+            self.fps = 0.0 if d is None else d['fps']
+            self.reported = 0 if d is None else len(self.frames) + d.get('short_by', 0)
+            self.i = 0
+
+        def read(self):
+            if self.i >= len(self.frames):
+                return False, None
+            self.i += 1
+            return True, self.frames[self.i - 1]
+
+        def get(self, prop):
+            return float(self.reported) if prop == _StandInCv2.CAP_PROP_FRAME_COUNT else self.fps
+
+        def release(self):
+            _StandInCv2.released += 1
+
+    @staticmethod
+    def cvtColor(image, code):
+        assert code == _StandInCv2.COLOR_BGR2RGB
+        return image[:, :, ::-1]
+
+
+def test_opencv_source_protocol_with_a_stand_in_cv2(tmp_path, monkeypatch):
+    """cv2 is not installed here, so the reference's decoder path (OpenCVFrameSource: first frame read at open, frame
+    count and rate from the container, BGR -> RGB, early end of stream, unreadable file) runs against a stand-in module
+    with cv2's call protocol; the frames it yields then go through the same batched loop as every other source"""
+    import sys
+    monkeypatch.setitem(sys.modules, 'cv2', _StandInCv2)
+    rgb = _frames(7, seed=4)
+    good = tmp_path / 'clip.mp4'
+    with open(good, 'wb') as f:
+        np.save(f, {'bgr': [fr[:, :, ::-1].copy() for fr in rgb], 'fps': 30.0}, allow_pickle=True)
+    src = PV.OpenCVFrameSource(str(good))
+    assert src.n_frames == 7 and src.frame_rate == 30.0
+    got = list(src)
+    assert len(got) == 7 and all(np.array_equal(a, b) for a, b in zip(got, rgb))         # RGB again, in order
+    src.close()
+    assert _StandInCv2.released == 1
+    # the container reports more frames than can be decoded: the source stops at the last good frame
+    short = tmp_path / 'short.mp4'
+    with open(short, 'wb') as f:
+        np.save(f, {'bgr': [fr[:, :, ::-1].copy() for fr in rgb[:4]], 'fps': 15.0, 'short_by': 3}, allow_pickle=True)
+    s2 = PV.OpenCVFrameSource(str(short))
+    assert s2.n_frames == 7 and len(list(s2)) == 4
+    s2.close()
+    # no decodable frame at all: loud failure at open, capture released
+    bad = tmp_path / 'bad.mp4'
+    bad.write_bytes(b'0')
+    with pytest.raises(RuntimeError, match='could not read a frame'):
+        PV.OpenCVFrameSource(str(bad))
+    with pytest.raises(FileNotFoundError):
+        PV.OpenCVFrameSource(str(tmp_path / 'missing.mp4'))
+    # through the video driver with the default source: same detections as the in-memory source, failed file reported
+    md = PV.run_detector_on_videos(PipelinedStub(), [('clip.mp4', str(good)), ('bad.mp4', str(bad))], every_n_frames=2, batch_size=3,
+                                   detection_threshold=0.0)
+    ref = PV.run_detector_on_frames(PipelinedStub(), PV.ArrayFrameSource(rgb, frame_rate=30.0), every_n_frames=2,
+                                    batch_size=3, detection_threshold=0.0)
+    assert md['frame_rates'] == [30.0, -1.0]
+    images = PV.video_results_to_md_format(md)
+    assert images[0]['frames_processed'] == [0, 2, 4, 6] and images[1]['detections'] is None
+    got_dets = sorted((d['frame_number'], d['conf'], tuple(d['bbox'])) for d in images[0]['detections'])
+    ref_dets = sorted((int(r['file'][5:11]), d['conf'], tuple(d['bbox'])) for r in ref['results'] for d in (r.get('detections') or []))
+    assert got_dets == ref_dets and len(got_dets) > 0
