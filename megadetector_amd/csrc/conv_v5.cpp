@@ -492,19 +492,22 @@ static const ConvCfg g_cfgs5[] = {
 };
 constexpr int kNumProf5 = 3;
 
-// ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp (same K order, same
-// results), then the developer variants
+// ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp and the C = 80
+// strip kernel of conv_v5c.cpp (same K order, same results), then the developer variants
 constexpr int kNumMain5 = (int)(sizeof(g_cfgs5) / sizeof(g_cfgs5[0])) - kNumProf5;
+static int first5c() { return kNumMain5 + conv5s_num_cfgs(); }
 
-int conv5_num_cfgs() { return kNumMain5 + conv5s_num_cfgs(); }
+int conv5_num_cfgs() { return first5c() + conv5c_num_cfgs(); }
 const ConvCfg& conv5_cfg(int i) {
     if (i < kNumMain5) return g_cfgs5[i];
-    if (i < conv5_num_cfgs()) return conv5s_cfg(i - kNumMain5);
-    return g_cfgs5[i - conv5s_num_cfgs()];
+    if (i < first5c()) return conv5s_cfg(i - kNumMain5);
+    if (i < conv5_num_cfgs()) return conv5c_cfg(i - first5c());
+    return g_cfgs5[i - conv5_num_cfgs() + kNumMain5];
 }
 
 hipError_t conv5_init() {
     hipError_t e = conv5s_init();
+    if (e == hipSuccess) e = conv5c_init();
 #define X(id, bm, bn, wm, wn, prof)                                                              \
     if (e == hipSuccess)                                                                       \
         e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof>,                \
@@ -519,14 +522,16 @@ bool conv5_supports(int cfg, const ConvArgs& a) {
     const bool ok = a.wgt4 != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H &&
                     a.Wo == a.W && a.C8 >= 8 && (a.N % 8) == 0 &&
                     (long long)(2 * a.W + conv5_cfg(cfg).bm + 16) * a.ld_in * 2 + 4096 < 0x7fffffffLL;
-    if (ok && cfg >= kNumMain5 && cfg < conv5_num_cfgs()) return conv5s_supports(cfg - kNumMain5, a);
+    if (ok && cfg >= kNumMain5 && cfg < first5c()) return conv5s_supports(cfg - kNumMain5, a);
+    if (ok && cfg >= first5c() && cfg < conv5_num_cfgs()) return conv5c_supports(cfg - first5c(), a);
     return ok;
 }
 
 hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     if (!conv5_supports(cfg, a)) return hipErrorInvalidValue;
-    if (cfg >= kNumMain5 && cfg < conv5_num_cfgs()) return conv5s_launch(cfg - kNumMain5, a, s);
-    if (cfg >= conv5_num_cfgs()) cfg -= conv5s_num_cfgs();        // developer variants
+    if (cfg >= kNumMain5 && cfg < first5c()) return conv5s_launch(cfg - kNumMain5, a, s);
+    if (cfg >= first5c() && cfg < conv5_num_cfgs()) return conv5c_launch(cfg - first5c(), a, s);
+    if (cfg >= conv5_num_cfgs()) cfg -= conv5_num_cfgs() - kNumMain5;        // developer variants
     const ConvCfg& c = g_cfgs5[cfg];
     ConvArgs p = a;
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;

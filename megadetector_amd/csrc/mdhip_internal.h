@@ -213,6 +213,11 @@ struct ConvCfg {
     bool conv5s_supports(int cfg, const ConvArgs& a); \
     hipError_t conv5s_launch(int cfg, const ConvArgs& a, hipStream_t s); \
     hipError_t conv5s_init(); \
+    int conv5c_num_cfgs(); \
+    const ConvCfg& conv5c_cfg(int i); \
+    bool conv5c_supports(int cfg, const ConvArgs& a); \
+    hipError_t conv5c_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv5c_init(); \
     int conv6_num_cfgs(); \
     const ConvCfg& conv6_cfg(int i); \
     bool conv6_supports(int cfg, const ConvArgs& a); \

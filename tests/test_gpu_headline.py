@@ -201,3 +201,41 @@ def test_stem_kernel_is_bit_identical_to_the_implicit_gemm(dtype):
             np.testing.assert_array_equal(ctx.read_layer(0, n), ref)
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_strip_kernel_is_bit_identical_to_the_row_segment_kernel(dtype):
+    """conv_v5c.cpp (the 80 -> 80 channel 3x3 convs of the first C3 block: weights in registers, a workgroup walking
+    down a column strip of the image through a ring of row segments) keeps conv_v5's K order and MFMA chains: the same
+    bits as conv_v5<192,80> for the whole network output and for the block's own output, on map widths that are and
+    are not multiples of its 160- / 128-pixel tiles (320, 160, 96, 48: one full, one half-empty, partial tiles), on
+    maps shorter than a row segment, with the residual, and for several images per batch."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    for (n, hh, ww) in ((1, 1280, 1280), (3, 384, 640), (2, 256, 384), (2, 128, 192)):
+        ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+        try:
+            strips = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith('v5:strip')]
+            assert len(strips) >= 2 and not any(ctx.cfg_is_bitwise(c) for c in strips)
+            classic = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == 'v5:run192x80/4x1/0'][0]
+            imgs = PU.random_images(n, hh, ww, seed=hh + 3 * ww)
+            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            ops = [o['op'] for o in ctx.op_infos() if o['kind'] == 0 and ctx.op_supports_cfg(o['op'], strips[0])]
+            names = [o['name'] for o in ctx.op_infos() if o['op'] in ops]
+            assert len(ops) == 4 and all('L2 C3.m' in s and 'cv2' in s for s in names), names      # the four bottleneck 3x3s
+            for op in ops:
+                ctx.set_op_cfg(op, classic)
+            ctx.forward(n, hh, ww)
+            ref_l2, ref_pred = ctx.read_layer(2, n).copy(), ctx.read_predictions(n).copy()
+            for cfg in strips:
+                for op in ops:
+                    assert ctx.op_supports_cfg(op, cfg)
+                    ctx.set_op_cfg(op, cfg)
+                ctx.forward(n, hh, ww)
+                ran = {ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['op'] in ops}
+                assert ran == {ctx.conv_cfg_name(cfg)}
+                np.testing.assert_array_equal(ctx.read_layer(2, n), ref_l2, err_msg=ctx.conv_cfg_name(cfg))
+                np.testing.assert_array_equal(ctx.read_predictions(n), ref_pred, err_msg=ctx.conv_cfg_name(cfg))
+        finally:
+            ctx.close()
