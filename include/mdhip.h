@@ -233,6 +233,11 @@ typedef struct {
     int32_t batch;          /* batch size the entry was measured at (<= 0: taken as 32) */
 } mdhip_tuned;
 int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n);
+/* Fused bottlenecks (default on): a C3 block whose 3x3 convs all resolve to a strip configuration (the 80-channel block
+ * of the x6 stack at batch >= 2) runs every bottleneck -- 1x1, SiLU, 3x3, SiLU, residual -- as ONE launch that keeps the
+ * hidden tensor on chip.  Same arithmetic and summation order as the two launches: bit-identical results.  on = 0 runs
+ * the two launches (A/B measurements, tests). */
+int mdhip_set_fuse(mdhip_ctx* ctx, int on);
 /* time one op in isolation: `iters` back-to-back launches bracketed by events */
 int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float* ms_avg,
                   void* hip_stream);

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -76,6 +77,9 @@ struct Op {
     bool f8_out = false, f8_in = false;
     int f8_peer = -1;
     float act_scale = 0.f, amax = 0.f;
+    // fused bottleneck (conv_v5c.cpp): fuse_role 1 = the 1x1 of bottleneck fuse_idx of C3 block fuse_group, 2 = its 3x3
+    int fuse_group = -1, fuse_idx = -1, fuse_role = 0;
+    double pre_flops = 0;
     size_t amax_off = 0;
     // the configuration chosen for the last (n, h, w): the table walk is not repeated on every launch
     int memo_n = 0, memo_h = 0, memo_w = 0, memo_cfg = -1;
@@ -127,6 +131,9 @@ struct mdhip_ctx {
     // to run; `calibrating` makes run_op execute every op in 16 bits and record the range of the tensors
     bool calibrated = false, calibrating = false;
     int n_f8 = 0;
+    // C3 blocks whose bottlenecks can run as one launch each (1x1 -> LDS -> 3x3): op indices of the 3x3s per block
+    std::vector<std::vector<int>> fuse_groups;
+    bool fuse_enabled = true, fuse_suspended = false;
     std::vector<hipEvent_t> events;
     std::vector<mdhip_tuned> tuned;   // measured tile choices (tools/autotune.py)
     // optional event pair around every mdhip_forward (bench.py's live roofline measurement)
@@ -433,6 +440,17 @@ struct Planner {
                         pc = pack({b2}, false);
                         snprintf(nm, sizeof(nm), "L%d C3.m%d.cv2 3x3", i, j);
                         add_conv(i, nm, T, Y1, pc, 1, 1, true, L.shortcut ? &Y1 : nullptr);
+                        if (ctx->dtype != MDHIP_DTYPE_FP8 && (L.n % 2) == 0) {
+                            // candidates for the fused bottleneck kernel (decided per forward from the 3x3s' tiles):
+                            // an even number of bottlenecks, so that ping-ponging Y1 <-> T ends in Y1
+                            const int o2 = (int)ctx->ops.size() - 1, o1 = o2 - 1;
+                            if (j == 0) ctx->fuse_groups.emplace_back();
+                            ctx->ops[o1].fuse_group = ctx->ops[o2].fuse_group = (int)ctx->fuse_groups.size() - 1;
+                            ctx->ops[o1].fuse_idx = ctx->ops[o2].fuse_idx = j;
+                            ctx->ops[o1].fuse_role = 1;
+                            ctx->ops[o2].fuse_role = 2;
+                            ctx->fuse_groups.back().push_back(o2);
+                        }
                         if (ctx->packed[pc].groups8 > 0) {
                             // fp8 mode: the hidden tensor T of this bottleneck travels as e4m3 (1x1 writes, 3x3 reads)
                             const int o2 = (int)ctx->ops.size() - 1, o1 = o2 - 1;
@@ -727,69 +745,132 @@ void fill_conv_args(mdhip_ctx* ctx, Op& op, int n, int h, int w, ConvArgs& a) {
                (double)pc.c_out * pc.k_real * 2.0 + (op.has_res ? (double)a.M * pc.c_out * 2.0 : 0.0);
 }
 
+// the tile configuration of a conv op for this call: forced (tests, autotune), remembered from the last call of the same
+// shape, or from the table (see below); -1 = none of them applies (the caller falls back to the heuristic)
+int select_cfg(mdhip_ctx* ctx, Op& op, const ConvArgs& a, int n, int h, int w, bool* from_table_out) {
+    int cfg = op.forced_cfg;
+    bool from_table = false;
+    const bool memo_hit = cfg < 0 && op.memo_cfg >= 0 && op.memo_n == n && op.memo_h == h && op.memo_w == w;
+    if (memo_hit) {
+        cfg = op.memo_cfg;
+        from_table = op.memo_from_table;
+    } else if (cfg < 0) {
+        const PackedConv& pc = ctx->packed[op.pc];
+        // 1. The canonical entry: same layer geometry (N, K, taps, stride, residual), per-image M equal
+        //    or nearest within 4x (the same layer at another image shape, e.g. 960x1280 instead of
+        //    1280x1280), largest batch among equals.  It fixes the kernel FAMILY (= fp32 summation
+        //    order) of the op -- per image, never per call, or an image's result would depend on the
+        //    batch it travels in.
+        // 2. Among the entries of that geometry, per-image M and family: the one measured at the
+        //    nearest total M (= nearest batch size).  Small batches want smaller tiles.
+        // 3. No entry within 4x of this call's total M: the fill-aware heuristic for the bitwise family,
+        //    the canonical configuration otherwise.
+        const double m_img = (double)a.M / n;
+        const mdhip_tuned* canon = nullptr;
+        double best = 1e30;
+        for (const mdhip_tuned& t : ctx->tuned) {
+            if (t.n != pc.c_out || t.k != pc.k_real || t.ntaps != a.ntaps || t.stride != a.stride ||
+                t.has_res != (op.has_res ? 1 : 0) || t.m <= 0)
+                continue;
+            const int tb = t.batch > 0 ? t.batch : 32;
+            const double t_img = (double)t.m / tb;
+            const double r = t_img > m_img ? t_img / m_img : m_img / t_img;
+            if (r > 4.0 || !conv_api(ctx).supports(t.cfg, a)) continue;
+            const int cb = canon ? (canon->batch > 0 ? canon->batch : 32) : 0;
+            if (r < best - 1e-9 || (r < best + 1e-9 && tb > cb)) {
+                best = r;
+                canon = &t;
+            }
+        }
+        if (canon) {
+            const bool fam = conv_cfg_is_bitwise_family(canon->cfg);
+            const double c_img = (double)canon->m / (canon->batch > 0 ? canon->batch : 32);
+            const mdhip_tuned* pick = nullptr;
+            double best_m = 1e30;
+            for (const mdhip_tuned& t : ctx->tuned) {
+                if (t.n != canon->n || t.k != canon->k || t.ntaps != canon->ntaps || t.stride != canon->stride ||
+                    t.has_res != canon->has_res || t.m <= 0 || conv_cfg_is_bitwise_family(t.cfg) != fam)
+                    continue;
+                const double t_img = (double)t.m / (t.batch > 0 ? t.batch : 32);
+                if (t_img < c_img * 0.999 || t_img > c_img * 1.001 || !conv_api(ctx).supports(t.cfg, a)) continue;
+                const double scaled = (double)t.m * (m_img / t_img);          // total M of that batch at this image shape
+                const double r = scaled > a.M ? scaled / a.M : a.M / scaled;
+                if (r < best_m) { best_m = r; pick = &t; }
+            }
+            if (pick && best_m <= 4.0) {
+                cfg = pick->cfg;
+                from_table = true;
+            } else if (!fam) {
+                cfg = canon->cfg;
+                from_table = true;
+            }                                   // else: heuristic below (bitwise family)
+        }
+    }
+    *from_table_out = from_table;
+    return cfg;
+}
+
+// ---- fused bottlenecks (conv_v5c.cpp) --------------------------------------------------------------------------
+// A C3 block runs its bottlenecks as one launch each (1x1 -> T in LDS -> 3x3 + residual) when every 3x3 of the block
+// resolves to a strip configuration for this call: the block then ping-pongs between its two buffers (Y1 -> T -> Y1 ..;
+// the fused kernel must not write the tensor it reads halos from), so it is all bottlenecks of a block or none.
+// Same arithmetic and K order as the two separate launches: the same bits.
+
+// the 3x3 `op` (bottleneck j of its block) as a fused launch: x = Y1 for even j, T for odd j
+void fused_args(mdhip_ctx* ctx, const Op& op, const Op& pre, ConvArgs& a) {
+    const Tensor& X = (op.fuse_idx % 2 == 0) ? op.out : op.in;
+    const Tensor& O = (op.fuse_idx % 2 == 0) ? op.in : op.out;
+    const PackedConv& pp = ctx->packed[pre.pc];
+    a.in = (const uint16_t*)(ctx->arena + X.off);
+    a.ld_in = X.ld;
+    a.out = ctx->arena + O.off;
+    a.ld_out = O.ld;
+    a.res = op.has_res ? a.in : nullptr;
+    a.ld_res = op.has_res ? X.ld : 0;
+    a.wgt_pre = (const uint16_t*)(ctx->warena + pp.w_off);
+    a.bias_pre = (const float*)(ctx->warena + pp.b_off);
+    a.k_pad_pre = pp.k_pad;
+}
+
+bool group_is_fused(mdhip_ctx* ctx, int group, int n, int h, int w) {
+    if (group < 0 || !ctx->fuse_enabled || ctx->fuse_suspended || ctx->calibrating || ctx->dtype == MDHIP_DTYPE_FP8) return false;
+    for (int oi : ctx->fuse_groups[group]) {
+        Op& op = ctx->ops[oi];
+        const Op& pre = ctx->ops[oi - 1];
+        const double f0 = op.flops, b0 = op.bytes;
+        ConvArgs a{};
+        fill_conv_args(ctx, op, n, h, w, a);
+        op.flops = f0; op.bytes = b0;
+        bool from_table = false;
+        int cfg = select_cfg(ctx, op, a, n, h, w, &from_table);
+        if (cfg < 0) cfg = choose_cfg_for(ctx, a);
+        if (cfg < 0 || strncmp(conv_api(ctx).cfg(cfg).name, "v5:strip", 8) != 0) return false;
+        fused_args(ctx, op, pre, a);
+        if (!conv_api(ctx).supports(cfg, a)) return false;
+    }
+    return true;
+}
+
 int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
     switch (op.kind) {
         case OP_CONV: {
-            ConvArgs a;
+            ConvArgs a{};
+            const bool fused = op.fuse_role != 0 && group_is_fused(ctx, op.fuse_group, n, h, w);
             fill_conv_args(ctx, op, n, h, w, a);
-            int cfg = op.forced_cfg;
-            bool from_table = false;
-            const bool memo_hit = cfg < 0 && op.memo_cfg >= 0 && op.memo_n == n && op.memo_h == h && op.memo_w == w;
-            if (memo_hit) {
-                cfg = op.memo_cfg;
-                from_table = op.memo_from_table;
-            } else if (cfg < 0) {
-                const PackedConv& pc = ctx->packed[op.pc];
-                // 1. The canonical entry: same layer geometry (N, K, taps, stride, residual), per-image M equal
-                //    or nearest within 4x (the same layer at another image shape, e.g. 960x1280 instead of
-                //    1280x1280), largest batch among equals.  It fixes the kernel FAMILY (= fp32 summation
-                //    order) of the op -- per image, never per call, or an image's result would depend on the
-                //    batch it travels in.
-                // 2. Among the entries of that geometry, per-image M and family: the one measured at the
-                //    nearest total M (= nearest batch size).  Small batches want smaller tiles.
-                // 3. No entry within 4x of this call's total M: the fill-aware heuristic for the bitwise family,
-                //    the canonical configuration otherwise.
-                const double m_img = (double)a.M / n;
-                const mdhip_tuned* canon = nullptr;
-                double best = 1e30;
-                for (const mdhip_tuned& t : ctx->tuned) {
-                    if (t.n != pc.c_out || t.k != pc.k_real || t.ntaps != a.ntaps || t.stride != a.stride ||
-                        t.has_res != (op.has_res ? 1 : 0) || t.m <= 0)
-                        continue;
-                    const int tb = t.batch > 0 ? t.batch : 32;
-                    const double t_img = (double)t.m / tb;
-                    const double r = t_img > m_img ? t_img / m_img : m_img / t_img;
-                    if (r > 4.0 || !conv_api(ctx).supports(t.cfg, a)) continue;
-                    const int cb = canon ? (canon->batch > 0 ? canon->batch : 32) : 0;
-                    if (r < best - 1e-9 || (r < best + 1e-9 && tb > cb)) {
-                        best = r;
-                        canon = &t;
-                    }
-                }
-                if (canon) {
-                    const bool fam = conv_cfg_is_bitwise_family(canon->cfg);
-                    const double c_img = (double)canon->m / (canon->batch > 0 ? canon->batch : 32);
-                    const mdhip_tuned* pick = nullptr;
-                    double best_m = 1e30;
-                    for (const mdhip_tuned& t : ctx->tuned) {
-                        if (t.n != canon->n || t.k != canon->k || t.ntaps != canon->ntaps || t.stride != canon->stride ||
-                            t.has_res != canon->has_res || t.m <= 0 || conv_cfg_is_bitwise_family(t.cfg) != fam)
-                            continue;
-                        const double t_img = (double)t.m / (t.batch > 0 ? t.batch : 32);
-                        if (t_img < c_img * 0.999 || t_img > c_img * 1.001 || !conv_api(ctx).supports(t.cfg, a)) continue;
-                        const double scaled = (double)t.m * (m_img / t_img);          // total M of that batch at this image shape
-                        const double r = scaled > a.M ? scaled / a.M : a.M / scaled;
-                        if (r < best_m) { best_m = r; pick = &t; }
-                    }
-                    if (pick && best_m <= 4.0) {
-                        cfg = pick->cfg;
-                        from_table = true;
-                    } else if (!fam) {
-                        cfg = canon->cfg;
-                        from_table = true;
-                    }                                   // else: heuristic below (bitwise family)
-                }
+            if (fused && op.fuse_role == 1) {            // this 1x1 runs inside the following 3x3's launch
+                op.last_cfg = -1;
+                op.pre_flops = op.flops;                  // accounted with the fused launch
+                op.flops = op.bytes = 0;
+                break;
             }
+            if (fused) {
+                const Op& pre = *(&op - 1);
+                fused_args(ctx, op, pre, a);
+                op.flops += pre.pre_flops;
+                op.bytes -= (double)a.M * a.N * 2.0;       // T is neither written nor read
+            }
+            bool from_table = false;
+            int cfg = select_cfg(ctx, op, a, n, h, w, &from_table);
             if (cfg < 0) cfg = choose_cfg_for(ctx, a);
             hipError_t le = conv_api(ctx).launch(cfg, a, s);
             if (le == hipErrorInvalidValue && from_table) {      // table entry from another build: not applicable
@@ -874,6 +955,7 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     if (device < 0 || device >= ndev) return fail(nullptr, MDHIP_EINVAL, "device %d outside [0,%d)", device, ndev);
 
     mdhip_ctx* ctx = new mdhip_ctx();
+    if (const char* ef = getenv("MDHIP_FUSE")) ctx->fuse_enabled = atoi(ef) != 0;      // A/B measurements
     ctx->device = device;
     ctx->dtype = dtype;
     ctx->max_batch = max_batch;
@@ -1336,6 +1418,8 @@ int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float*
     }
     ctx->cur_tta = DecodeTta();
     ctx->cur_A = num_anchors_for(ctx, h, w);
+    // one op in isolation: a bottleneck's two convs as the two launches they are (no fusion)
+    struct Suspend { mdhip_ctx* c; Suspend(mdhip_ctx* c_) : c(c_) { c->fuse_suspended = true; } ~Suspend() { c->fuse_suspended = false; } } suspend(ctx);
     if (int rc = run_op(ctx, ctx->ops[op], n, h, w, s)) return rc;    // warm
     HIP_TRY(ctx, hipEventRecord(ctx->events[0], s));
     for (int i = 0; i < iters; ++i)
@@ -1496,7 +1580,7 @@ int mdhip_num_conv_cfgs(void) { return conv_num_cfgs(); }
 int mdhip_op_supports_cfg(mdhip_ctx* ctx, int op, int cfg) {
     if (!ctx || op < 0 || op >= (int)ctx->ops.size()) return MDHIP_EINVAL;
     if (ctx->ops[op].kind != OP_CONV || cfg < 0 || cfg >= conv_num_cfgs()) return 0;
-    ConvArgs a;
+    ConvArgs a{};
     const int h = ctx->last_h ? ctx->last_h : ctx->max_stride, w = ctx->last_w ? ctx->last_w : ctx->max_stride;
     fill_conv_args(ctx, ctx->ops[op], ctx->last_n ? ctx->last_n : 1, h, w, a);
     return conv_api(ctx).supports(cfg, a) ? 1 : 0;
@@ -1513,6 +1597,12 @@ int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n) {
             return fail(ctx, MDHIP_EINVAL, "tuned entry %d: cfg %d outside [0,%d)", i, entries[i].cfg, conv_num_cfgs());
     ctx->tuned.assign(entries, entries + n);
     for (Op& op : ctx->ops) op.memo_cfg = -1;
+    return MDHIP_OK;
+}
+
+int mdhip_set_fuse(mdhip_ctx* ctx, int on) {
+    if (!ctx) return MDHIP_EINVAL;
+    ctx->fuse_enabled = on != 0;
     return MDHIP_OK;
 }
 

@@ -164,6 +164,11 @@ struct ConvArgs {
     float out_qscale;
     void* dbg;              // instrumentation output of the profiling variants (tools/convbench.cpp), else nullptr
     int dev_param;          // free parameter of the developer variants (tools/convbench.cpp: env MDHIP_DEV_PARAM)
+    // conv_v5c.cpp, fused bottleneck: the 1x1 conv in front of this 3x3 ([n_rows][k_pad_pre] 16-bit weights, k = input
+    // channel; fp32 bias); nullptr = plain 3x3
+    const uint16_t* wgt_pre;
+    const float*    bias_pre;
+    int k_pad_pre;
 };
 
 struct ConvCfg {

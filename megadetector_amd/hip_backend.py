@@ -282,6 +282,10 @@ class HipContext:
     def set_op_cfg(self, op, cfg):
         self._check(self.lib.mdhip_set_op_cfg(self.h, op, cfg), 'mdhip_set_op_cfg')
 
+    def set_fuse(self, on):
+        """fused bottleneck launches on (default) / off (the 1x1 and the 3x3 as two launches: same bits)"""
+        self._check(self.lib.mdhip_set_fuse(self.h, 1 if on else 0), 'mdhip_set_fuse')
+
     def op_supports_cfg(self, op, cfg):
         return self.lib.mdhip_op_supports_cfg(self.h, int(op), int(cfg)) == 1
 

@@ -76,6 +76,24 @@ def force_batch32_tiles(ctx, n, h, w):
     return forced
 
 
+def _ran_tiles(ctx, forced):
+    """{op: name of the tile configuration its last launch used}.  A 1x1 that ran inside the following 3x3's fused
+    launch (conv_v5c.cpp; cfg -1) is reported with the tile it was forced to, after checking that it is one of the
+    bottleneck 1x1s of the 80-channel block and that the 3x3 behind it ran a strip configuration."""
+    infos = ctx.op_infos()
+    ran = {}
+    for k, o in enumerate(infos):
+        if o['kind'] != 0:
+            continue
+        if o['cfg'] < 0:
+            nxt = infos[k + 1]
+            assert 'L2 C3.m' in o['name'] and 'cv1' in o['name'] and ctx.conv_cfg_name(nxt['cfg']).startswith('v5:strip'), o
+            ran[o['op']] = forced[o['op']]
+        else:
+            ran[o['op']] = ctx.conv_cfg_name(o['cfg'])
+    return ran
+
+
 def _layers_against_oracle(ctx, W, imgs, hh, ww, emulate, max_tol, mean_tol):
     x, _ = PU.oracle_input(imgs, max(hh, ww), 64)
     assert tuple(x.shape[2:]) == (hh, ww)
@@ -113,7 +131,7 @@ def test_headline_topology_every_layer_with_the_benchmarked_tiles(dtype):
         n_convs = sum(1 for o in ctx.op_infos() if o['kind'] == 0)
         assert n_convs == 152 and len(forced) == n_convs, (n_convs, len(forced))
         ctx.forward(2, HH, WW)
-        ran = {o['op']: ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['kind'] == 0}
+        ran = _ran_tiles(ctx, forced)
         assert ran == forced                                         # the ops really ran the benchmarked kernels
         used = sorted(set(ran.values()))
         print('{}: benchmarked tile configurations in use: {}'.format(dtype, used))
@@ -157,7 +175,7 @@ def test_headline_configuration_one_full_size_image_through_the_detector():
     assert len(forced) == 152
     res = det.generate_detections_one_image(im, 'full.jpg', detection_threshold=thr)
     assert 'failure' not in res
-    ran = {o['op']: ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['kind'] == 0}
+    ran = _ran_tiles(ctx, forced)
     assert ran == forced
     pred_hip = ctx.read_predictions(1)
     assert pred_hip.shape == (1, 102000, 8) and np.isfinite(pred_hip).all()
@@ -237,5 +255,54 @@ def test_strip_kernel_is_bit_identical_to_the_row_segment_kernel(dtype):
                 assert ran == {ctx.conv_cfg_name(cfg)}
                 np.testing.assert_array_equal(ctx.read_layer(2, n), ref_l2, err_msg=ctx.conv_cfg_name(cfg))
                 np.testing.assert_array_equal(ctx.read_predictions(n), ref_pred, err_msg=ctx.conv_cfg_name(cfg))
+        finally:
+            ctx.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_fused_bottleneck_is_bit_identical_to_the_two_launches(dtype):
+    """conv_v5c.cpp's fused kernel (1x1 -> hidden tensor in LDS -> 3x3 + residual, the block ping-ponging between its two
+    buffers) against the same four bottlenecks as 1x1 and strip-3x3 launches (mdhip_set_fuse 0): same arithmetic, same
+    summation order -> the same bits, in the block's output and in the predictions, for plain and augmented forwards,
+    on full, half-empty and partial tiles, maps shorter than a row segment and several images per batch; and an
+    image's result does not depend on the batch it travels in while fused."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    for (n, hh, ww) in ((1, 1280, 1280), (3, 384, 640), (2, 256, 384), (2, 128, 192)):
+        ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+        try:
+            strip = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith('v5:strip')][0]
+            imgs = PU.random_images(n, hh, ww, seed=2 * hh + ww)
+            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            ops = [o['op'] for o in ctx.op_infos() if o['kind'] == 0 and ctx.op_supports_cfg(o['op'], strip)]
+            assert len(ops) == 4
+            for op in ops:
+                ctx.set_op_cfg(op, strip)
+            ctx.set_fuse(False)
+            ctx.forward(n, hh, ww)
+            assert all(o['cfg'] >= 0 for o in ctx.op_infos() if o['kind'] == 0)             # every conv launched
+            ref_l2, ref_pred = ctx.read_layer(2, n).copy(), ctx.read_predictions(n).copy()
+            ctx.forward_tta(n, hh, ww)
+            ref_tta = ctx.read_predictions(n).copy()
+            ctx.set_fuse(True)
+            ctx.forward(n, hh, ww)
+            skipped = [o['name'] for o in ctx.op_infos() if o['kind'] == 0 and o['cfg'] < 0]
+            assert len(skipped) == 4 and all('L2 C3.m' in s and 'cv1' in s for s in skipped), skipped   # the four 1x1s ran inside the 3x3 launches
+            np.testing.assert_array_equal(ctx.read_layer(2, n), ref_l2)
+            np.testing.assert_array_equal(ctx.read_predictions(n), ref_pred)
+            ctx.forward_tta(n, hh, ww)
+            np.testing.assert_array_equal(ctx.read_predictions(n), ref_tta)
+            if n > 1:                                                                     # batch invariance, fused
+                ctx.preprocess([imgs[n - 1]], _identity_geoms([imgs[n - 1]]), hh, ww)
+                ctx.forward(1, hh, ww)
+                np.testing.assert_array_equal(ctx.read_predictions(1)[0], ref_pred[n - 1])
+            # one bottleneck forced to another tile: the block falls back to eight launches, same bits (same family)
+            classic = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == 'v5:run192x80/4x1/0'][0]
+            ctx.set_op_cfg(ops[1], classic)
+            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            ctx.forward(n, hh, ww)
+            assert all(o['cfg'] >= 0 for o in ctx.op_infos() if o['kind'] == 0)
+            np.testing.assert_array_equal(ctx.read_predictions(n), ref_pred)
         finally:
             ctx.close()

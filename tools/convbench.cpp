@@ -234,7 +234,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(h_ref8.data(), d_ref8, out_elems * 2, hipMemcpyDeviceToHost));
     }
 
-    ConvArgs a;
+    ConvArgs a{};
     memset(&a, 0, sizeof(a));
     a.in = d_in; a.wgt = d_w; a.bias = d_b; a.out = d_out; a.res = sh->res ? d_res : nullptr; a.zero = d_zero;
     a.ld_in = sh->cin; a.ld_out = sh->cout; a.ld_res = sh->cout;
