@@ -127,7 +127,9 @@ def test_fp8_headline_topology_layers():
         imgs = PU.structured_images(2, HH, WW, seed=91)
         ctx.preprocess(imgs, _identity_geoms(imgs), HH, WW)
         ctx.calibrate(2, HH, WW)
-        assert ctx.lib.mdhip_fp8_num_tensors(ctx.h) == 56                 # 4 + 8 + 12 + 4 + 4 backbone, 6 x 4 head
+        # 8 + 12 + 4 + 4 backbone, 6 x 4 head; the four bottlenecks of the 80-channel block (layer 2) stay in 16 bits:
+        # they run as fused launches (conv_v5c.cpp), faster than their e4m3 pair and exact
+        assert ctx.lib.mdhip_fp8_num_tensors(ctx.h) == 52
         ctx.forward(2, HH, WW)
         x, _ = PU.oracle_input(imgs, WW, 64)
         keep = {}
@@ -138,7 +140,7 @@ def test_fp8_headline_topology_layers():
             rows.append((i, emax, emean))
         print('fp8 x6: worst layer error max {:.2e} mean {:.2e}; per layer: {}'.format(
             max(t[1] for t in rows), max(t[2] for t in rows), ' '.join('L{}:{:.1e}/{:.1e}'.format(*t) for t in rows)))
-        # x6 depth (56 e4m3 tensors, up to 12 bottlenecks per C3): the flips accumulate further, measured worst
+        # x6 depth (52 e4m3 tensors, up to 12 bottlenecks per C3): the flips accumulate further, measured worst
         # 4.5e-2 / 3.2e-2; a dropped channel group or tap would be >= 1e-1 in the layer it happens
         bad = [t for t in rows if t[1] > 8e-2 or t[2] > 5e-2]
         assert not bad, bad
