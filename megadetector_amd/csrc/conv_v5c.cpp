@@ -50,7 +50,7 @@ constexpr int kPixB = 160;                                     // bytes per pixe
 constexpr int c80_run_bytes(int bm) { return ((bm + 2) * kPixB + 1023) & ~1023; }
 constexpr int kW1Bytes = 9 * 80 * 32;                          // the 16-channel group's weights: 9 taps x 80 rows x 32 B
 // zero region read by the lanes that hold k 16..31 of the 16-channel group (base + the largest immediate of a fragment)
-constexpr int c80_zero_bytes(int fm) { return ((15 + fm * 16 + 2) * kPixB + 16 + 255) & ~255; }      // (fm + 1 fragments: the fused kernel's conversion)
+constexpr int c80_zero_bytes(int fm) { return ((15 + fm * 16 + 2) * kPixB + 32 + 255) & ~255; }      // (fm + 1 fragments: the fused kernel's conversion)
 constexpr int c80_lds_bytes(int bm, int wm) { return 4 * c80_run_bytes(bm) + kW1Bytes + c80_zero_bytes(bm / (16 * wm)) + 320 + 1024; }
 constexpr int c80f_lds_bytes(int bm, int wm) { return c80_lds_bytes(bm, wm) + 80 * 192 + 320; }
 constexpr int c80_blocks(int bm, int wm) { return 163840 / c80_lds_bytes(bm, wm) >= 2 && wm == 1 ? 2 : 1; }
@@ -137,7 +137,9 @@ conv_c80_kernel(const ConvArgs p) {
     // ---- fragment addresses: base of kernel row r (ring slot of image row y - 1 + r) + immediates -----------------------
     const unsigned lane_a = (unsigned)((wm * (BM / WM) + m15) * kPixB + kb * 16);
     const unsigned lane_a1 = kb < 2 ? lane_a + 128u : 0xffffffffu;       // 16-channel group: chunks 8, 9 of the pixel
-    const unsigned lane_z = (unsigned)(ZERO_OFF + m15 * kPixB);
+    // (the same 160-byte pixel pitch and 16-byte chunk offset as the real rows: without the chunk term the lanes of
+    // k-chunks 2 and 3 collide pairwise on their banks -- PMC: 21 % of the LDS cycles were conflicts)
+    const unsigned lane_z = (unsigned)(ZERO_OFF + m15 * kPixB + (kb & 1) * 16);
     const unsigned lane_w1 = kb < 2 ? (unsigned)(W1_OFF + (wn * 16 + m15) * 32 + kb * 16) : (unsigned)ZERO_OFF;
     const unsigned lane_w1_step = kb < 2 ? 80u * 32u : 0u;
 
@@ -329,7 +331,9 @@ conv_c80f_kernel(const ConvArgs p) {
 
     const unsigned lane_a = (unsigned)((wm * (BM / WM) + m15) * kPixB + kb * 16);
     const unsigned lane_a1 = kb < 2 ? lane_a + 128u : 0xffffffffu;
-    const unsigned lane_z = (unsigned)(ZERO_OFF + m15 * kPixB);
+    // (the same 160-byte pixel pitch and 16-byte chunk offset as the real rows: without the chunk term the lanes of
+    // k-chunks 2 and 3 collide pairwise on their banks -- PMC: 21 % of the LDS cycles were conflicts)
+    const unsigned lane_z = (unsigned)(ZERO_OFF + m15 * kPixB + (kb & 1) * 16);
     const unsigned lane_w1 = kb < 2 ? (unsigned)(W1_OFF + (wn * 16 + m15) * 32 + kb * 16) : (unsigned)ZERO_OFF;
     const unsigned lane_w1_step = kb < 2 ? 80u * 32u : 0u;
     // conversion: this wave's pixel fragments of the staged row are wm*TFW .. (TF - 1 at most)
