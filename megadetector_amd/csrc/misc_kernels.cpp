@@ -368,6 +368,7 @@ hipError_t launch_absmax_view(const uint16_t* in, int ld, int c, long long pixel
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// one thread per (image, anchor, pixel): the general form (any number of anchors / outputs)
 __global__ void __launch_bounds__(256)
 detect_decode_kernel(const float* __restrict__ logits, int ld, float* __restrict__ pred, int n,
                      int ny, int nx, int na, int no, int n_anchors, int level_off, float stride,
@@ -400,9 +401,54 @@ detect_decode_kernel(const float* __restrict__ logits, int ld, float* __restrict
     for (int i = 4; i < no; ++i) o[i] = sigmoid_f32(l[i]);
 }
 
+// MegaDetector's head (3 anchors x 8 outputs = 24 floats per pixel): one thread per (image, pixel) reads its pixel's 96
+// contiguous bytes once (the general kernel's threads read 32 of every 96 bytes, three times over) and writes the
+// three anchors' rows; the same arithmetic, statement for statement: the same bits.
+__global__ void __launch_bounds__(256)
+detect_decode_3x8_kernel(const float* __restrict__ logits, int ld, float* __restrict__ pred, int n,
+                         int ny, int nx, int n_anchors, int level_off, float stride,
+                         const float* __restrict__ anchors_px, DecodeTta tta) {
+    const long long total = (long long)n * ny * nx;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % nx);
+    const int y = (int)((t / nx) % ny);
+    const int b = (int)(t / ((long long)nx * ny));
+    const float4* lp = (const float4*)(logits + ((size_t)(b * ny + y) * nx + x) * ld);
+    float4 v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = lp[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int idx = level_off + (a * ny + y) * nx + x;
+        if (idx < tta.keep_from || idx >= tta.keep_to) continue;
+        const float4 p = v[2 * a], q = v[2 * a + 1];
+        const float s0 = sigmoid_f32(p.x), s1 = sigmoid_f32(p.y);
+        const float s2 = sigmoid_f32(p.z), s3 = sigmoid_f32(p.w);
+        float cx = (s0 * 2.0f + ((float)x - 0.5f)) * stride;
+        float cy = (s1 * 2.0f + ((float)y - 0.5f)) * stride;
+        const float w2 = s2 * 2.0f, h2 = s3 * 2.0f;
+        float bw = (w2 * w2) * anchors_px[a * 2 + 0];
+        float bh = (h2 * h2) * anchors_px[a * 2 + 1];
+        if (tta.scale != 1.0f) {
+            cx /= tta.scale; cy /= tta.scale; bw /= tta.scale; bh /= tta.scale;
+        }
+        if (tta.flip_lr) cx = tta.img_w - cx;
+        float4* o = (float4*)(pred + ((size_t)b * n_anchors + tta.out_off + (idx - tta.keep_from)) * 8);
+        o[0] = make_float4(cx, cy, bw, bh);
+        o[1] = make_float4(sigmoid_f32(q.x), sigmoid_f32(q.y), sigmoid_f32(q.z), sigmoid_f32(q.w));
+    }
+}
+
 hipError_t launch_detect_decode(const float* logits, int ld, float* pred, int n, int ny, int nx,
                                 int na, int no, int n_anchors, int level_off, float stride,
                                 const float* anchors_px, const DecodeTta& tta, hipStream_t s) {
+    if (na == 3 && no == 8 && (ld % 4) == 0 && ((uintptr_t)logits % 16) == 0 && ((uintptr_t)pred % 16) == 0) {
+        const long long total = (long long)n * ny * nx;
+        hipLaunchKernelGGL(detect_decode_3x8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           logits, ld, pred, n, ny, nx, n_anchors, level_off, stride, anchors_px, tta);
+        return hipGetLastError();
+    }
     const long long total = (long long)n * na * ny * nx;
     hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        logits, ld, pred, n, ny, nx, na, no, n_anchors, level_off, stride, anchors_px, tta);
