@@ -306,3 +306,45 @@ def test_fused_bottleneck_is_bit_identical_to_the_two_launches(dtype):
             np.testing.assert_array_equal(ctx.read_predictions(n), ref_pred)
         finally:
             ctx.close()
+
+
+def test_strip_and_fused_kernels_on_other_80_channel_blocks():
+    """the strip / fused kernels are not tied to layer 2 of the x6 stack: a P5 network at width 0.625 / depth 0.67 has
+    an 80-channel C3 with shortcut and FOUR bottlenecks at stride 8 (layer 4) and one WITHOUT shortcut and TWO
+    bottlenecks in the head (layer 17: no residual operand, nc = 5 -> the general decode kernel behind it).  Both must
+    run fused (1x1s absorbed), bit-identical to the separate launches and to conv_v5, and within the layer
+    tolerance of the storage-emulating oracle."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    yaml = yolo_yaml.make_yaml(0.67, 0.625, nc=5, p6=False)
+    W = weights_io.synthetic_weights(yaml, seed=7)
+    n, hh, ww = 2, 256, 384
+    ctx = HipContext(W, device=0, dtype='bf16', max_batch=n, max_h=hh, max_w=ww)
+    try:
+        strips = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith('v5:strip')]
+        imgs = PU.structured_images(n, hh, ww, seed=12)
+        ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+        infos = ctx.op_infos()
+        ops = [o['op'] for o in infos if o['kind'] == 0 and ctx.op_supports_cfg(o['op'], strips[0])]
+        names = [o['name'] for o in infos if o['op'] in ops]
+        assert len(ops) == 6 and sum('L4 ' in s for s in names) == 4 and sum('L17 ' in s for s in names) == 2, names
+        assert [bool(o['has_res']) for o in infos if o['op'] in ops] == [True] * 4 + [False] * 2
+        classic = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == 'v5:run128x80/4x1/0'][0]
+        for op in ops:
+            ctx.set_op_cfg(op, classic)
+        ctx.forward(n, hh, ww)
+        ref = ctx.read_predictions(n).copy()
+        for cfg in strips:
+            for op in ops:
+                ctx.set_op_cfg(op, cfg)
+            for fuse in (False, True):
+                ctx.set_fuse(fuse)
+                ctx.forward(n, hh, ww)
+                skipped = [o['name'] for o in ctx.op_infos() if o['kind'] == 0 and o['cfg'] < 0]
+                assert len(skipped) == (6 if fuse else 0), (fuse, skipped)
+                np.testing.assert_array_equal(ctx.read_predictions(n), ref, err_msg='{} fuse={}'.format(ctx.conv_cfg_name(cfg), fuse))
+        # against the oracle, layer by layer, in the fused state
+        worst, e_box, e_conf, _, _ = _layers_against_oracle(ctx, W, imgs, hh, ww, True, LAYER_MAX_TOL, LAYER_MEAN_TOL)
+        print('width-0.625 P5 net, fused 80-channel blocks: worst layer error max {:.2e} mean {:.2e}'.format(*worst))
+    finally:
+        ctx.close()
