@@ -235,8 +235,9 @@ typedef struct {
 int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n);
 /* Fused bottlenecks (default on): a C3 block whose 3x3 convs all resolve to a strip configuration (the 80-channel block
  * of the x6 stack at batch >= 2) runs every bottleneck -- 1x1, SiLU, 3x3, SiLU, residual -- as ONE launch that keeps the
- * hidden tensor on chip.  Same arithmetic and summation order as the two launches: bit-identical results.  on = 0 runs
- * the two launches (A/B measurements, tests). */
+ * hidden tensor on chip; and a 1x1 conv behind Upsample + Concat reads the low-resolution tensor in place instead of its
+ * 4x copy (the upsample launch is skipped).  Same arithmetic and summation order: bit-identical results.  on = 0 runs
+ * the separate launches (A/B measurements, tests). */
 int mdhip_set_fuse(mdhip_ctx* ctx, int on);
 /* time one op in isolation: `iters` back-to-back launches bracketed by events */
 int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float* ms_avg,

@@ -65,7 +65,9 @@ constexpr int v2_waves_per_simd(int bm, int bn, int nw) {
 
 // PROF = 1: timing-only instrumentation (s_memtime at the phase boundaries of every step, summed per
 // wave and written to p.dbg); used by tools/convbench.cpp, never by the product path
-template <int BM, int BN, int WM, int WN, int PROF = 0>
+// UP = the variant that reads the first K slabs of a 1x1 conv from a low-resolution tensor (nearest-neighbour upsample in
+// place, ConvArgs::in_up); its own instantiation so that the loader of every other launch stays as it was
+template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false>
 __global__ void __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BM, BN, WM * WN))
 conv_v2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -118,6 +120,11 @@ conv_v2_kernel(const ConvArgs p) {
     __amdgpu_buffer_rsrc_t a_rsrc = b_rsrc;
     unsigned a_off[A_PER];
     uint32_t a_mask[A_PER];
+    // nearest-neighbour upsample read in place (1x1 convs only): the slabs [0, up_slabs) of K come from the low-resolution
+    // producer of the concatenated input's first part, at this lane's pixel halved
+    const int up_slabs = UP ? p.up_slabs : 0;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(UP ? p.in_up : p.in), 0, kNumRecords, 0x00020000);
+    [[maybe_unused]] unsigned u_off[UP ? A_PER : 1];
     // position of this lane's 16-byte chunk inside K (valid for C8 >= 8: at most one tap wrap per slab)
     int c8 = 0, ts = 0;
     uint32_t tapbit = 1;
@@ -128,7 +135,7 @@ conv_v2_kernel(const ConvArgs p) {
     const unsigned wrap_c = (unsigned)(p.ld_in * 2 - p.C8 * 16);        // next tap, same row
     const unsigned wrap_r = (unsigned)((p.W - p.kw) * p.ld_in * 2);     // first tap of the next kernel row
 
-    auto init_tile = [&](int tile_m) {
+    auto init_tile = [&](int tile_m) __attribute__((always_inline)) {
         const int m0 = tile_m * BM;
         const int b0 = m0 / p.HoWo;
         const int rem0 = m0 - b0 * p.HoWo;
@@ -151,6 +158,8 @@ conv_v2_kernel(const ConvArgs p) {
                 const int ix0 = ox * p.stride - p.pad;
                 const long long px = (long long)(b * p.H + iy0) * p.W + ix0;
                 off = (unsigned)((px - base_px) * p.ld_in * 2);
+                if constexpr (UP)
+                    u_off[i] = (unsigned)((((long long)b * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.ld_up * 2 + jj * 16);
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -166,7 +175,7 @@ conv_v2_kernel(const ConvArgs p) {
     };
 
     // the loader moves on by one slab (branch-free inside a tile)
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
         if (++l_kt == KT) {
             l_kt = 0;
             if (l_tile == last_tile) {
@@ -192,12 +201,18 @@ conv_v2_kernel(const ConvArgs p) {
     };
 
     // one LDS-DMA piece of the loader's current slab into stage `buf`
-    auto dma_a = [&](int buf, int i) {
+    auto dma_a = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
+        if constexpr (UP) {
+            if (l_kt < up_slabs) {                                               // wave-uniform
+                MDHIP_DMA16(u_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, (a_mask[i] & tapbit) ? u_off[i] : kOOB, l_kt * 128);
+                return;
+            }
+        }
         const unsigned voff = (a_mask[i] & tapbit) ? a_off[i] + tapoff : kOOB;
         MDHIP_DMA16(a_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, voff, 0);
     };
-    auto dma_b = [&](int buf, int i) {
+    auto dma_b = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
         if (B_RAGGED && i == B_PER - 1 && wave >= B_INSTR % NW) return;     // wave-uniform
         const unsigned voff = l_live ? b_off[i] : kOOB;
@@ -518,11 +533,18 @@ hipError_t conv2_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
     MDHIP_CONV2_PROF(X)
 #undef X
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<160, 160, 2, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)g_cfgs2[0].lds_bytes);
     return e;
 }
 
 bool conv2_supports(const ConvArgs& a) {
     // the branch-free K walk needs at least one whole slab per tap; the epilogue stores 4 channels
+    // (in_up goes with configuration 0 only: the family table in conv_igemm.cpp checks the id)
+    if (a.in_up && !(a.ntaps == 1 && a.stride == 1 && (a.H % 2) == 0 && (a.W % 2) == 0 && a.up_slabs > 0 &&
+                     a.up_slabs * 8 <= a.C8 && !a.in_f8))
+        return false;
     return a.C8 >= 8 && a.kw <= 3 && a.ntaps <= 9 && (a.k_pad % 64) == 0;
 }
 
@@ -535,6 +557,10 @@ hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     p.tiles_per_xcd = (p.tiles_m + 7) / 8;
     p.m_streams = std::max(1, std::min(p.tiles_per_xcd, (32 * c.blocks_per_cu) / p.tiles_n));
     const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
+    if (a.in_up) {                                     // upsample read in place: configuration 0 (160x160) only
+        hipLaunchKernelGGL((conv_v2_kernel<160, 160, 2, 2, 0, true>), grid, dim3(256), c.lds_bytes, s, p);
+        return hipGetLastError();
+    }
     switch (cfg) {
 #define X(id, bm, bn, wm, wn)                                                                        \
     case id:                                                                                       \

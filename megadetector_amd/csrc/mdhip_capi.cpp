@@ -80,6 +80,8 @@ struct Op {
     // fused bottleneck (conv_v5c.cpp): fuse_role 1 = the 1x1 of bottleneck fuse_idx of C3 block fuse_group, 2 = its 3x3
     int fuse_group = -1, fuse_idx = -1, fuse_role = 0;
     double pre_flops = 0;
+    // upsample read in place (conv_v2.cpp): an OP_UPSAMPLE whose only reader is the 1x1 conv `up_peer` (and vice versa)
+    int up_peer = -1;
     size_t amax_off = 0;
     // the configuration chosen for the last (n, h, w): the table walk is not repeated on every launch
     int memo_n = 0, memo_h = 0, memo_w = 0, memo_cfg = -1;
@@ -580,6 +582,27 @@ struct Planner {
                 }
             }
         }
+        // an upsample whose output is the first part of a concatenated tensor that exactly one op reads, a 1x1 / stride 1
+        // conv: that conv can read the low-resolution tensor in place (conv_v2.cpp) and the upsample need not run
+        for (size_t u = 0; u < ctx->ops.size(); ++u) {
+            Op& up = ctx->ops[u];
+            if (up.kind != OP_UPSAMPLE) continue;
+            int reader = -1, readers = 0;
+            for (size_t k = 0; k < ctx->ops.size(); ++k) {
+                const Op& o = ctx->ops[k];
+                if (o.kind == OP_DECODE) continue;
+                const bool overlaps = o.in.off == up.out.off || (o.has_res && o.res.off == up.out.off);
+                if (k != u && overlaps) { ++readers; reader = (int)k; }
+            }
+            if (readers != 1) continue;
+            Op& c = ctx->ops[reader];
+            const PackedConv& pc = ctx->packed[c.pc >= 0 ? c.pc : 0];
+            if (c.kind == OP_CONV && reader > (int)u && c.stride == 1 && pc.kh == 1 && pc.kw == 1 && !c.f8_in &&
+                c.in.off == up.out.off && c.in.ld == up.out.ld && c.in.c > up.out.c && c.in.div == up.out.div) {
+                up.up_peer = reader;
+                c.up_peer = (int)u;
+            }
+        }
         return true;
     }
 };
@@ -854,12 +877,41 @@ bool group_is_fused(mdhip_ctx* ctx, int group, int n, int h, int w) {
     return true;
 }
 
+// the 1x1 conv `conv` reads the first channels of its concatenated input from the low-resolution tensor of the upsample
+// op in front of it (which is then not run) when its tile configuration is one of conv_v2.cpp's
+void up_args(mdhip_ctx* ctx, const Op& up, ConvArgs& a) {
+    a.in_up = (const uint16_t*)(ctx->arena + up.in.off);
+    a.ld_up = up.in.ld;
+    a.up_slabs = up.in.c / 64;
+}
+
+bool up_is_absorbed(mdhip_ctx* ctx, Op& conv, int n, int h, int w) {
+    if (conv.up_peer < 0 || !ctx->fuse_enabled || ctx->fuse_suspended) return false;
+    const Op& up = ctx->ops[conv.up_peer];
+    if (up.in.c % 64) return false;
+    const double f0 = conv.flops, b0 = conv.bytes;
+    ConvArgs a{};
+    fill_conv_args(ctx, conv, n, h, w, a);
+    conv.flops = f0; conv.bytes = b0;
+    bool from_table = false;
+    int cfg = select_cfg(ctx, conv, a, n, h, w, &from_table);
+    if (cfg < 0) cfg = choose_cfg_for(ctx, a);
+    if (cfg < 0 || strncmp(conv_api(ctx).cfg(cfg).name, "v2:", 3) != 0) return false;
+    up_args(ctx, up, a);
+    return conv_api(ctx).supports(cfg, a);
+}
+
 int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
     switch (op.kind) {
         case OP_CONV: {
             ConvArgs a{};
             const bool fused = op.fuse_role != 0 && group_is_fused(ctx, op.fuse_group, n, h, w);
+            const bool up_in_place = op.up_peer >= 0 && up_is_absorbed(ctx, op, n, h, w);
             fill_conv_args(ctx, op, n, h, w, a);
+            if (up_in_place) {
+                up_args(ctx, ctx->ops[op.up_peer], a);
+                op.bytes -= (double)a.M * ctx->ops[op.up_peer].in.c * 2.0 * 0.75;      // a quarter of those pixels is read
+            }
             if (fused && op.fuse_role == 1) {            // this 1x1 runs inside the following 3x3's launch
                 op.last_cfg = -1;
                 op.pre_flops = op.flops;                  // accounted with the fused launch
@@ -900,6 +952,10 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             break;
         }
         case OP_UPSAMPLE: {
+            if (op.up_peer >= 0 && up_is_absorbed(ctx, ctx->ops[op.up_peer], n, h, w)) {     // read in place by its consumer
+                op.bytes = 0;
+                break;
+            }
             const int H = h / op.in.div, W = w / op.in.div;
             op.bytes = (double)n * H * W * op.in.c * 2.0 * 5.0;
             HIP_TRY(ctx, launch_upsample2x((const uint16_t*)(ctx->arena + op.in.off), op.in.ld,

@@ -169,6 +169,11 @@ struct ConvArgs {
     const uint16_t* wgt_pre;
     const float*    bias_pre;
     int k_pad_pre;
+    // conv_v2.cpp, 1x1 convs behind Upsample + Concat: the first up_slabs 64-channel slabs of K are read from the
+    // LOW-resolution tensor in_up (pixel (y, x) -> (y / 2, x / 2), pixel pitch ld_up) instead of their 4x copy in the
+    // concat buffer; nullptr = everything from `in`
+    const uint16_t* in_up;
+    int ld_up, up_slabs;
 };
 
 struct ConvCfg {

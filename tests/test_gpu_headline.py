@@ -289,6 +289,7 @@ def test_fused_bottleneck_is_bit_identical_to_the_two_launches(dtype):
             ctx.forward(n, hh, ww)
             skipped = [o['name'] for o in ctx.op_infos() if o['kind'] == 0 and o['cfg'] < 0]
             assert len(skipped) == 4 and all('L2 C3.m' in s and 'cv1' in s for s in skipped), skipped   # the four 1x1s ran inside the 3x3 launches
+            # (mdhip_set_fuse also switches the upsample-read-in-place of the head's 1x1 convs: the same equality covers it)
             np.testing.assert_array_equal(ctx.read_layer(2, n), ref_l2)
             np.testing.assert_array_equal(ctx.read_predictions(n), ref_pred)
             ctx.forward_tta(n, hh, ww)
