@@ -133,3 +133,31 @@ def test_host_e4m3_quantiser_matches_torch():
     got_f = torch.from_numpy(out).view(torch.float8_e4m3fn).to(torch.float32).numpy()
     want_f = torch.from_numpy(want).view(torch.float8_e4m3fn).to(torch.float32).numpy()
     np.testing.assert_array_equal(got_f, want_f)
+
+
+@pytest.mark.parametrize('table', ['tuned_cfgs.json', 'tuned_cfgs_fp16.json', 'tuned_cfgs_fp8.json'])
+def test_shipped_tile_tables_name_configurations_of_this_build(table):
+    """every entry of the shipped tile tables names a configuration the library has (entries are resolved by name at
+    load time and silently dropped when unknown: a typo would cost speed, not correctness -- so it is checked here);
+    per layer geometry the entries of all batch sizes are of one kernel family (an image's result must not depend on
+    the batch it travels in); and the 80-channel block has its strip configuration at batch 32"""
+    import json
+    from megadetector_amd import _lib
+    lib = _lib.load()
+    names = {lib.mdhip_conv_cfg_name(i).decode(): i for i in range(lib.mdhip_num_conv_cfgs())}
+    entries = json.load(open(os.path.join(REPO, 'megadetector_amd', table)))['entries']
+    assert len(entries) > 100
+    unknown = sorted({e['name'] for e in entries if e.get('name') and e['name'] not in names})
+    assert not unknown, unknown
+    fam = {}
+    for e in entries:
+        if not e.get('name'):
+            continue
+        per_img = round(e['m'] / max(1, e.get('batch', 32)))
+        f8 = e['name'].startswith('f8:')                 # (the fp8 table holds e4m3 AND 16-bit entries of a geometry:
+        key = (e['n'], e['k'], e['ntaps'], e['stride'], e['has_res'], per_img, f8)      # an op supports only one kind)
+        fam.setdefault(key, set()).add(bool(lib.mdhip_cfg_is_bitwise(names[e['name']])))
+    mixed = {k: v for k, v in fam.items() if len(v) > 1}
+    assert not mixed, mixed
+    strip = [e for e in entries if e['n'] == 80 and e['k'] == 720 and e['ntaps'] == 9 and e['has_res'] == 1 and e.get('batch') == 32]
+    assert strip and all(e['name'].startswith('v5:strip') for e in strip), strip
