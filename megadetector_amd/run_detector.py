@@ -16,31 +16,62 @@ import os
 from .constants import (FAILURE_INFER, FAILURE_IMAGE_OPEN, CONF_DIGITS, COORD_DIGITS,          # noqa: F401
                         DEFAULT_DETECTOR_LABEL_MAP, DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD)
 
-# reference run_detector.py:88-137 (order matters: first match wins)
-model_string_to_model_version = {
-    'mdv5a': 'v5a.0.1', 'mdv5b': 'v5b.0.1',
-    'v5a.0.0': 'v5a.0.1', 'v5b.0.0': 'v5b.0.1', 'v5a.0.1': 'v5a.0.1', 'v5b.0.1': 'v5b.0.1',
-    'md1000-redwood': 'v1000.0.0-redwood', 'md1000-spruce': 'v1000.0.0-spruce',
-    'mdv1000-redwood': 'v1000.0.0-redwood', 'mdv1000-spruce': 'v1000.0.0-spruce',
-    'v1000-redwood': 'v1000.0.0-redwood', 'v1000-spruce': 'v1000.0.0-spruce',
-    'redwood': 'v1000.0.0-redwood', 'spruce': 'v1000.0.0-spruce',
-    'mdv5': 'v5a.0.1', 'md5': 'v5a.0.1', 'mdv1000': 'v1000.0.0-redwood', 'md1000': 'v1000.0.0-redwood',
-    'default': 'v5a.0.1', 'megadetector': 'v5a.0.1',
-}
+# reference run_detector.py:88-137: filename substrings -> canonical version.  Order matters (the first matching
+# key wins), so the table is generated in the reference's order: exact versions, the three spellings of the MDv1000
+# family, bare tree names (no "sorrel": the reference has none), opinionated defaults.
+_V1000 = ('redwood', 'cedar', 'larch', 'sorrel', 'spruce')
+model_string_to_model_version = {}
+model_string_to_model_version.update({'mdv2': 'v2.0.0', 'mdv3': 'v3.0.0', 'mdv4': 'v4.1.0',
+                                      'mdv5a': 'v5a.0.1', 'mdv5b': 'v5b.0.1',
+                                      'v2': 'v2.0.0', 'v3': 'v3.0.0', 'v4': 'v4.1.0', 'v4.1': 'v4.1.0',
+                                      'v5a.0.0': 'v5a.0.1', 'v5b.0.0': 'v5b.0.1',
+                                      'v5a.0.1': 'v5a.0.1', 'v5b.0.1': 'v5b.0.1'})
+for _prefix in ('md1000-', 'mdv1000-', 'v1000-'):
+    model_string_to_model_version.update({_prefix + t: 'v1000.0.0-' + t for t in _V1000})
+model_string_to_model_version.update({t: 'v1000.0.0-' + t for t in ('redwood', 'spruce', 'cedar', 'larch')})
+model_string_to_model_version.update({'mdv5': 'v5a.0.1', 'md5': 'v5a.0.1', 'mdv1000': 'v1000.0.0-redwood',
+                                      'md1000': 'v1000.0.0-redwood', 'default': 'v5a.0.1',
+                                      'megadetector': 'v5a.0.1'})
 
-# the YOLOv5-family entries of reference run_detector.py:152-248 (what write_results_to_file
-# copies into info.detector_metadata)
+# reference run_detector.py:140-248: what write_results_to_file copies -- key for key, in this key order -- into
+# info.detector_metadata (pinned against the real table by tests/test_host_path_reference.py)
+_GH = 'https://github.com/agentmorris/MegaDetector/releases/download/'
+_LILA = 'https://lila.science/public/models/megadetector/'
+model_url_base = os.environ.get('MD_MODEL_URL_BASE') or (_GH + 'v1000.0/')
+if not model_url_base.endswith('/'):
+    model_url_base += '/'
+
+
+def _tf(url):
+    return {'url': url, 'typical_detection_threshold': 0.8, 'conservative_detection_threshold': 0.3,
+            'model_type': 'tf', 'normalized_typical_inference_speed': 1.0 / 3.5}
+
+
+def _v5(name, md5):
+    return {'url': _GH + 'v5.0/' + name, 'typical_detection_threshold': 0.2, 'conservative_detection_threshold': 0.05,
+            'image_size': 1280, 'model_type': 'yolov5', 'normalized_typical_inference_speed': 1.0, 'md5': md5}
+
+
+def _v1000(tree, speed, md5, **extra):
+    d = {'url': model_url_base + 'md_v1000.0.0-{}.pt'.format(tree), 'normalized_typical_inference_speed': speed,
+         'md5': md5}
+    d.update(extra)
+    return d
+
+
 known_models = {
-    'v5a.0.0': {'typical_detection_threshold': 0.2, 'conservative_detection_threshold': 0.05,
-                'image_size': 1280, 'model_type': 'yolov5', 'md5': 'ec1d7603ec8cf642d6e0cd008ba2be8c'},
-    'v5b.0.0': {'typical_detection_threshold': 0.2, 'conservative_detection_threshold': 0.05,
-                'image_size': 1280, 'model_type': 'yolov5', 'md5': 'bc235e73f53c5c95e66ea0d1b2cbf542'},
-    'v5a.0.1': {'typical_detection_threshold': 0.2, 'conservative_detection_threshold': 0.05,
-                'image_size': 1280, 'model_type': 'yolov5', 'md5': '60f8e7ec1308554df258ed1f4040bc4f'},
-    'v5b.0.1': {'typical_detection_threshold': 0.2, 'conservative_detection_threshold': 0.05,
-                'image_size': 1280, 'model_type': 'yolov5', 'md5': 'f17ed6fedfac2e403606a08c89984905'},
-    'v1000.0.0-redwood': {'typical_detection_threshold': 0.3, 'md5': '74474b3aec9cf1a990da38b37ddf9197'},
-    'v1000.0.0-spruce': {'md5': '1c9d1d2b3ba54931881471fdd508e6f2'},
+    'v2.0.0': _tf(_LILA + 'megadetector_v2.pb'),
+    'v3.0.0': _tf(_LILA + 'megadetector_v3.pb'),
+    'v4.1.0': _tf(_GH + 'v4.1/md_v4.1.0.pb'),
+    'v5a.0.0': _v5('md_v5a.0.0.pt', 'ec1d7603ec8cf642d6e0cd008ba2be8c'),
+    'v5b.0.0': _v5('md_v5b.0.0.pt', 'bc235e73f53c5c95e66ea0d1b2cbf542'),
+    'v5a.0.1': _v5('md_v5a.0.1.pt', '60f8e7ec1308554df258ed1f4040bc4f'),
+    'v5b.0.1': _v5('md_v5b.0.1.pt', 'f17ed6fedfac2e403606a08c89984905'),
+    'v1000.0.0-redwood': _v1000('redwood', 1.0, '74474b3aec9cf1a990da38b37ddf9197', typical_detection_threshold=0.3),
+    'v1000.0.0-spruce': _v1000('spruce', 12.7, '1c9d1d2b3ba54931881471fdd508e6f2'),
+    'v1000.0.0-larch': _v1000('larch', 2.4, 'cab94ebd190c2278e12fb70ffd548b6d'),
+    'v1000.0.0-cedar': _v1000('cedar', 2.0, '3d6472c9b95ba687b59ebe255f7c576b'),
+    'v1000.0.0-sorrel': _v1000('sorrel', 7.0, '4339a2c8af7a381f18ded7ac2a4df03e'),
 }
 
 

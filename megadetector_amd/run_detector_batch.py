@@ -490,6 +490,10 @@ def load_and_run_detector_batch(model_file, image_file_names, checkpoint_path=No
         raise NotImplementedError('class_mapping_filename / include_exif_tags are not part of the HIP hot path')
     if n_cores is not None and n_cores > 1:
         print('Warning: n_cores is ignored when running on a GPU (reference :1204)')
+    if confidence_threshold is None:
+        confidence_threshold = DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD
+    if checkpoint_frequency is None or checkpoint_path is None:
+        checkpoint_frequency = -1
     if results is None:
         results = []
     already_processed = set(r['file'] for r in results)
@@ -515,16 +519,27 @@ def load_and_run_detector_batch(model_file, image_file_names, checkpoint_path=No
     gc.collect()
     gc.freeze()
 
-    since_checkpoint = [0]
+    # Checkpoint cadence, as the reference has it: the in-line loops write when the number of images handed to the
+    # detector in THIS run is a multiple of the frequency (:1314, :1338 -- with batches, only when a batch boundary
+    # lands on a multiple); the queue consumer writes whenever a multiple has been crossed (:272-288).
+    counts = {'images': 0, 'last_checkpoint': 0}
+    crossing_rule = bool(use_image_queue)
 
-    def on_results(new_results):
+    def on_results(new_results, n_images=None):
         results.extend(new_results)
-        since_checkpoint[0] += len(new_results)
-        if checkpoint_path is not None and checkpoint_frequency != -1 and \
-                since_checkpoint[0] >= checkpoint_frequency:
-            print('Writing a new checkpoint after having processed {} images since last restart'.format(len(results)))
+        before = counts['images']
+        counts['images'] = before + (len(new_results) if n_images is None else n_images)
+        if checkpoint_path is None or checkpoint_frequency is None or checkpoint_frequency <= 0:
+            return
+        if crossing_rule:
+            due = counts['images'] // checkpoint_frequency > counts['last_checkpoint'] // checkpoint_frequency
+        else:
+            due = counts['images'] % checkpoint_frequency == 0
+        if due:
+            print('Writing a new checkpoint after having processed {} images since last restart'.format(
+                counts['images']))
             write_checkpoint(checkpoint_path, results)
-            since_checkpoint[0] = 0
+            counts['last_checkpoint'] = counts['images']
 
     if use_image_queue and not use_threads_for_queue and len(image_files) > 0:
         _run_detector_with_shared_ring(image_files, detector, confidence_threshold, quiet, image_size,
@@ -538,7 +553,7 @@ def load_and_run_detector_batch(model_file, image_file_names, checkpoint_path=No
     elif batch_size > 1:
         for batch in _group_into_batches(image_files, batch_size):
             on_results(_process_batch(batch, detector, confidence_threshold, quiet, image_size,
-                                      include_image_size, include_image_timestamp, None, augment))
+                                      include_image_size, include_image_timestamp, None, augment), len(batch))
     else:
         for im_file in image_files:
             on_results([_process_image(im_file, detector, confidence_threshold, quiet=quiet, image_size=image_size,

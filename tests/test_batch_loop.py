@@ -17,45 +17,7 @@ from megadetector_amd import run_detector_batch as RDB
 from megadetector_amd import run_detector
 
 
-class StubDetector:
-    """Deterministic fake of the 3-method detector interface (reference tf_detector.py:136 shows the
-    minimal duck type); detections are a pure function of the pixels, so any orchestration must
-    give identical output."""
-
-    default_image_size = 1280
-    letterbox_stride = 64
-
-    def __init__(self, fail_on=None):
-        self.fail_on = fail_on or set()
-        self.batches = []
-
-    def _one(self, img, name):
-        if isinstance(img, dict):
-            img = img['img_original']
-        a = np.asarray(img)
-        if a.ndim != 3:
-            return {'file': name, 'detections': None, 'failure': 'image access failure'}
-        s = int(a.astype(np.int64).sum())
-        dets = []
-        for k in range(s % 4 + 1):
-            conf = ((s >> (3 * k)) % 1000) / 1000.0
-            dets.append({'category': str(1 + (s + k) % 3), 'conf': conf,
-                         'bbox': [0.1 * k, 0.05, 0.2, 0.3]})
-        return {'file': name, 'detections': dets, 'max_detection_conf': max(d['conf'] for d in dets)}
-
-    def generate_detections_one_batch(self, imgs, names, detection_threshold=1e-5, image_size=None,
-                                      augment=False, verbose=False):
-        self.batches.append(len(imgs))
-        if any(n in self.fail_on for n in names):
-            raise RuntimeError('simulated device failure')
-        return [self._one(i, n) for i, n in zip(imgs, names)]
-
-    def generate_detections_one_image(self, img, name='unknown', detection_threshold=1e-5, image_size=None,
-                                      augment=False, verbose=False):
-        r = self._one(img, name)
-        if r.get('detections') is not None:
-            r['detections'] = [d for d in r['detections'] if d['conf'] >= detection_threshold]
-        return r
+from stub_detector import StubDetector  # noqa: E402
 
 
 @pytest.fixture()
