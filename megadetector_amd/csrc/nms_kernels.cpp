@@ -289,6 +289,10 @@ nms_image_kernel(const float* __restrict__ pred_all, int n_anchors, int no, floa
             if (total_alive == 0 || nk >= max_det) break;
             const int group = min(total_alive, 64);
             int nk_new = nk;
+            // wavefront 0 clears bits of alive[0] below: every wavefront must have taken its loop-top reading of
+            // those words first, or a late one could see the round's candidates already gone, leave the loop and
+            // miss the barriers the others still go through
+            __syncthreads();
             if (wave == 0) {
                 // lane l takes the l-th alive candidate of the chunk
                 int idx = -1;

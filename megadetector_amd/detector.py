@@ -20,6 +20,9 @@ augment=True runs yolov5's augmented inference (three scaled / flipped passes) o
 (mdhip_forward_tta).
 """
 
+import json
+import os
+
 import numpy as np
 
 from . import weights_io
@@ -141,11 +144,26 @@ class HIPDetector:
                                max_batch=self.max_batch, max_h=max_size, max_w=max_size)
         self.model = self._ctx
         self._fp8_pending = False
+        self._fp8_scales_file = opts.get('fp8_scales_file') or None
         if self._ctx.dtype == 'fp8':
-            if opts.get('fp8_scales'):
-                self._ctx.set_fp8_scales([float(v) for v in opts['fp8_scales']])
-            else:
+            scales = opts.get('fp8_scales')
+            if isinstance(scales, str):                       # "a;b;c" from a key=value command line
+                scales = [v for v in scales.replace(';', ' ').split() if v]
+            if not scales and self._fp8_scales_file and os.path.isfile(self._fp8_scales_file):
+                with open(self._fp8_scales_file, 'r') as f:
+                    scales = json.load(f)['fp8_scales']
+            if scales:
+                self._ctx.set_fp8_scales([float(v) for v in scales])
+            elif parse_bool_string(opts.get('fp8_calibrate_on_first_batch', False)):
+                # explicit opt-in: the static scales then come from whatever batch arrives first, i.e. the output
+                # depends on file order / batch size / shard; with fp8_scales_file they are saved for the next run
                 self._fp8_pending = True
+            else:
+                raise ValueError(
+                    "dtype 'fp8' needs its activation scales: pass detector_options['fp8_scales'] (a list saved from "
+                    "HipContext.fp8_scales) or ['fp8_scales_file'] (json written by an earlier calibration), or opt "
+                    "into calibrating on the first batch with ['fp8_calibrate_on_first_batch']=True -- results then "
+                    "depend on that batch")
 
     # -----------------------------------------------------------------------------------
     def preprocess_image(self, img_original, image_id='unknown', image_size=None, verbose=False):
@@ -284,6 +302,14 @@ class HIPDetector:
             results[original_idx] = {'file': current_id, 'detections': detections,
                                      'max_detection_conf': max_conf}
 
+    def _fp8_calibrated(self):
+        self._fp8_pending = False
+        if self._fp8_scales_file:
+            tmp = '{}.{}.tmp'.format(self._fp8_scales_file, os.getpid())
+            with open(tmp, 'w') as f:
+                json.dump({'fp8_scales': [float(sc) for sc, _, _ in self._ctx.fp8_scales()]}, f)
+            os.replace(tmp, self._fp8_scales_file)
+
     def _process_batch_group(self, group_items, results, detection_threshold, augment, verbose):
         """reference pytorch_detector.py:1257-1426 with the device work in libmdhip.so"""
         if len(group_items) == 0:
@@ -293,9 +319,9 @@ class HIPDetector:
         n = len(group_items)
         ctx = self._ctx
         ctx.preprocess(images, geoms, h, w)
-        if self._fp8_pending:               # fp8 mode without saved scales: this batch calibrates them
+        if self._fp8_pending:               # fp8 mode, explicit opt-in: this batch calibrates the scales
             ctx.calibrate(n, h, w)
-            self._fp8_pending = False
+            self._fp8_calibrated()
         if augment:
             ctx.forward_tta(n, h, w)        # yolov5 _forward_augment: 3 passes, concatenated predictions
         else:
@@ -321,7 +347,7 @@ class HIPDetector:
                             'consumed': [None, None], 'count': 0}
         return self._pl
 
-    def _submit_group(self, group_items, detection_threshold):
+    def _submit_group(self, group_items, detection_threshold, augment=False):
         pl = self._pipeline()
         torch = pl['torch']
         h, w = group_items[0][1]['img_processed'].shape[:2]
@@ -360,14 +386,17 @@ class HIPDetector:
             ctx.preprocess([base + off for off in offs], geoms, h, w, stream=comp.cuda_stream)
             if self._fp8_pending:
                 ctx.calibrate(n, h, w, stream=comp.cuda_stream)
-                self._fp8_pending = False
+                self._fp8_calibrated()
             ev = torch.cuda.Event()
             ev.record(comp)
             pl['consumed'][k] = ev
             # NMS + D2H behind the forward on the compute stream.  (Round 1 ran them on their own stream next to the
             # following batch's forward; measured in round 2: the 1024-thread NMS workgroups keep the persistent conv
             # workgroups off their CUs, the forward slows by more than the NMS costs in line: 37.6 vs 37.2 ms / step.)
-            ctx.forward(n, h, w, stream=comp.cuda_stream)
+            if augment:
+                ctx.forward_tta(n, h, w, stream=comp.cuda_stream)
+            else:
+                ctx.forward(n, h, w, stream=comp.cuda_stream)
             ctx.nms_enqueue(n, detection_threshold, self._nms_iou(), 300, slot=nms_slot, stream=comp.cuda_stream)
             done = torch.cuda.Event()
             done.record(comp)
@@ -378,8 +407,10 @@ class HIPDetector:
         det_all, counts = self._ctx.nms_wait(slot=handle['slot'])
         self._format_group(handle['items'], det_all, counts, handle['h'], handle['w'], results, detection_threshold)
 
-    def start_batch(self, img_original, image_id, detection_threshold=0.00001, image_size=None, verbose=False):
-        """Enqueues a batch; returns a ticket for finish_batch().  At most two tickets may be outstanding."""
+    def start_batch(self, img_original, image_id, detection_threshold=0.00001, image_size=None, augment=False,
+                    verbose=False):
+        """Enqueues a batch; returns a ticket for finish_batch().  At most two tickets may be outstanding.
+        Same arguments as generate_detections_one_batch (augment = yolov5's three-pass augmented inference)."""
         if self._ctx is None:
             raise RuntimeError('this HIPDetector was created with preprocess_only')
         if detection_threshold is None:
@@ -392,7 +423,7 @@ class HIPDetector:
         pending = None
         for ci, chunk in enumerate(chunks):
             try:
-                handle = self._submit_group(chunk, detection_threshold)
+                handle = self._submit_group(chunk, detection_threshold, augment)
                 if ci == len(chunks) - 1:
                     pending = handle                     # the last group stays in flight
                 else:

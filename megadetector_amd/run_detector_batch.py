@@ -667,6 +667,21 @@ def run_sharded(model_file, image_file_names, n_gpus, results=None, worker=None,
     todo = [f for f in files if f not in done]
     if n_gpus <= 1:
         return load_and_run_detector_batch(model_file, files, results=results, **kwargs)
+    dopts = kwargs.get('detector_options') or {}
+    if isinstance(dopts, (list, str)):
+        dopts = parse_kvp_list(dopts)
+    if str(dopts.get('dtype', '')).lower() == 'fp8' and not dopts.get('fp8_scales') and not (
+            dopts.get('fp8_scales_file') and os.path.isfile(dopts['fp8_scales_file'])):
+        # every shard would calibrate its e4m3 scales on its own first batch: the same image would get different
+        # detections depending on n_gpus
+        raise ValueError("dtype 'fp8' on several GPUs needs saved scales (detector_options fp8_scales or an existing "
+                         "fp8_scales_file): calibrate once on one GPU first")
+    ck = kwargs.get('checkpoint_path')
+    if ck is not None and results and (kwargs.get('checkpoint_frequency') or -1) > 0:
+        # The shards only know their own new results, and their `<ck>.shard<g>` files are about to be overwritten by
+        # this run's first checkpoints (a resumed run is split i % n again): keep everything restored so far in the
+        # plain file, which load_sharded_checkpoints unions with the shard files -- a second crash loses nothing.
+        write_checkpoint(ck, results)
     ctx = mp.get_context('spawn')
     out_q = ctx.Queue()
     shards = shard_image_list(todo, n_gpus)

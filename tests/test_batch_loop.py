@@ -314,6 +314,14 @@ def test_sharded_run_writes_one_checkpoint_per_shard_and_resumes(image_dir, tmp_
     marked = [dict(r, marker=1) for r in restored]
     full = RDB.run_sharded('stub', names, 2, results=marked, worker=_stub_shard_worker, quiet=True)
     assert sum(1 for r in full if r.get('marker') == 1) == 8
+    # a resumed run with the same checkpoint path overwrites the shard files of the first run; what it
+    # restored must survive a SECOND crash (kept in the plain file, which load_sharded_checkpoints unions)
+    second = RDB.run_sharded('stub', names[:10], 2, results=restored, worker=_stub_shard_worker,
+                             checkpoint_path=ck, checkpoint_frequency=1, quiet=True)
+    assert len(second) == 10
+    after_second = RDB.load_sharded_checkpoints(ck, 2)
+    assert set(r['file'] for r in after_second) == set(names[:10])
+    assert len(after_second) == 10                                   # no duplicates in the union
 
 
 def test_dead_shard_raises_instead_of_hanging(image_dir):

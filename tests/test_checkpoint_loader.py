@@ -77,6 +77,58 @@ def test_refuses_foreign_classes(tmp_path):
     assert 'refusing' in str(ei.value) or 'posix' in str(ei.value) or 'nt' in str(ei.value)
 
 
+class _NestedPayload:
+    """REDUCEs torch.storage._load_from_bytes(<torch.save blob>): an unrestricted torch.load inside the file"""
+
+    def __init__(self, marker):
+        self.marker = marker
+
+    def __reduce__(self):
+        import io
+
+        class Inner:
+            def __init__(self, marker):
+                self.marker = marker
+
+            def __reduce__(self):
+                return (open, (self.marker, 'w'))
+        buf = io.BytesIO()
+        torch.save(Inner(self.marker), buf)
+        return (torch.storage._load_from_bytes, (buf.getvalue(),))
+
+
+def test_refuses_nested_unpickle_gadgets(tmp_path):
+    """_load_from_bytes (a nested, unrestricted torch.load) and object-dtype numpy scalars (a nested
+    pickle.loads on older numpy) must not be reachable from a checkpoint file"""
+    import pickle
+    marker = str(tmp_path / 'payload_ran')
+    p = str(tmp_path / 'nested.pt')
+    torch.save({'model': _NestedPayload(marker)}, p)
+    with pytest.raises(Exception) as ei:
+        weights_io.load_checkpoint(p)
+    assert 'refusing' in str(ei.value) and '_load_from_bytes' in str(ei.value)
+    assert not os.path.exists(marker)
+
+    class ObjectScalar:
+        def __reduce__(self):
+            try:
+                from numpy._core.multiarray import scalar
+            except ImportError:
+                from numpy.core.multiarray import scalar
+            return (scalar, (np.dtype('O'), pickle.dumps({'x': 1})))
+    p2 = str(tmp_path / 'objscalar.pt')
+    torch.save({'model': ObjectScalar()}, p2)
+    with pytest.raises(Exception) as ei:
+        weights_io.load_checkpoint(p2)
+    assert 'refusing' in str(ei.value)
+    # plain numeric scalars (yolov5 checkpoints carry np.float64 fitness values) still load
+    p3 = str(tmp_path / 'okscalar.pt')
+    torch.save({'best_fitness': np.float64(0.5), 'model': None}, p3)
+    with open(p3, 'rb') as f:
+        d = torch.load(f, map_location='cpu', pickle_module=weights_io._PickleModule(), weights_only=False)
+    assert float(d['best_fitness']) == 0.5
+
+
 def test_oracle_forward_equals_independent_module_at_x6_width(tmp_path):
     """
     The oracle's functional forward (oracle/yolov5.py: the checker of every conv-stack parity test) against a second,
