@@ -128,6 +128,10 @@ def main():
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # one rank per GPU: CPUs of the GPU's NUMA node, disjoint from the other ranks' (the host thread formats 2.8 ms of
+    # detections per step and keeps the queue fed; SURVEY.md 8(e) "scaling limiter")
+    from megadetector_amd import placement
+    pinned_cpus = placement.pin_worker(local_rank, 1 if one_gpu else world, verbose=(world > 1))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -155,7 +159,7 @@ def main():
         ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
 
     # synthetic uint8 RGB batches, resident in HBM before the timed region
-    n_batches = 4
+    n_batches = 8                               # K >= 8 distinct batches, cycled
     gen = torch.Generator(device='cuda')
     batches = []
     for i in range(n_batches):

@@ -50,8 +50,10 @@ __device__ __forceinline__ float silu_f32(float x) {
 }
 
 constexpr int v5_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
-// 2 run buffers + 2 weight stages + 1 KiB holding the row of zeros
-constexpr int v5_lds_bytes(int bm, int bn) { return 2 * v5_run_pieces(bm) * 1024 + 2 * bn * 128 + 1024; }
+// the row of zeros (256 bytes) and, behind it, the staged bias of the workgroup's BN channels: whole KiB
+constexpr int v5_zero_bytes(int bn) { return (256 + bn * 4 + 1023) / 1024 * 1024; }
+// 2 run buffers + 2 weight stages + the zero row / bias area
+constexpr int v5_lds_bytes(int bm, int bn) { return 2 * v5_run_pieces(bm) * 1024 + 2 * bn * 128 + v5_zero_bytes(bn); }
 constexpr int v5_blocks_per_cu(int bm, int bn, int nw) {
     int b = 163840 / v5_lds_bytes(bm, bn);
     if (b > 8 / nw) b = 8 / nw;          // two waves per SIMD (256 registers each)
@@ -111,7 +113,7 @@ conv_v5_kernel(const ConvArgs p) {
     // the row of zeros that invalid (pixel, tap) pairs read; behind it (offset 256 of the same KiB) the bias of this
     // workgroup's BN output channels, staged once: the epilogue of every tile reads its 4 channels per fragment column
     // with one ds_read_b128 instead of a scalar load + wait per column (5 dependent round trips per tile)
-    static_assert(BN * 4 + 256 <= 1024, "bias staging area");
+    static_assert(BN * 4 + 256 <= v5_zero_bytes(BN), "bias staging area");
     if (tid < 16) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
     for (int c = tid; c < BN; c += NW * 64)
         *(__attribute__((address_space(3))) float*)(smem + ZERO_OFF + 256 + c * 4) = (n0 + c < p.n_rows) ? p.bias[n0 + c] : 0.f;
@@ -121,17 +123,25 @@ conv_v5_kernel(const ConvArgs p) {
     const int jj = (lane & 7) ^ lr;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.wgt4 + (size_t)n0 * p.k_pad4), 0, kNumRecords, 0x00020000);
-    unsigned b_off[B_PER];
+    // LEAN (the 8-wave tiles, which have no register to spare): one offset register for the wave's first piece, the
+    // others are that + i * NW * 8 rows; needs every row of the tile to exist (conv5_supports: n_rows % BN == 0)
+    constexpr bool LEAN = FM == 5 && FN == 5;
+    unsigned b_off[LEAN ? 1 : B_PER];
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
+    for (int i = 0; i < (LEAN ? 1 : B_PER); ++i) {
         const int row = (i * NW + wave) * 8 + lr;
-        b_off[i] = (row < BN && n0 + row < p.n_rows) ? (unsigned)(row * p.k_pad4 + jj * 8) * 2u : kOOB;
+        b_off[i] = (LEAN || (row < BN && n0 + row < p.n_rows)) ? (unsigned)(row * p.k_pad4 + jj * 8) * 2u : kOOB;
     }
+    const unsigned b_stride = (unsigned)(NW * 8 * p.k_pad4) * 2u;      // (LEAN) bytes between a wave's pieces
     int l_step = 0;                                // the weight loader's step inside a tile (same for every tile)
+    auto b_voff = [&](int i) __attribute__((always_inline)) -> unsigned {
+        if constexpr (LEAN) return b_off[0] + (unsigned)i * b_stride;
+        else return b_off[i];
+    };
     auto dma_b_piece = [&](int stage, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
         if ((B_PIECES % NW) != 0 && i == B_PER - 1 && wave >= B_PIECES % NW) return;           // wave-uniform
-        MDHIP_DMA16(b_rsrc, smem + B_OFF + stage * B_BYTES + (i * NW + wave) * 1024, b_off[i], l_step * 128);
+        MDHIP_DMA16(b_rsrc, smem + B_OFF + stage * B_BYTES + (i * NW + wave) * 1024, b_voff(i), l_step * 128);
     };
     auto dma_b_done = [&]() __attribute__((always_inline)) { l_step = (l_step + 1 == steps_per_tile) ? 0 : l_step + 1; };
 
@@ -140,12 +150,17 @@ conv_v5_kernel(const ConvArgs p) {
     // the whole batch), channels cg*64 .. cg*64+63.  Pixels outside the batch read zeros; pixels that
     // are inside the batch but outside the image for some tap are dealt with at the fragment read.
     __amdgpu_buffer_rsrc_t a_rsrc = b_rsrc;
-    unsigned q_off[A_PER];                         // byte offset of this lane's pixel + chunk from the run's first pixel
+    unsigned q_off[LEAN ? 1 : A_PER];              // byte offset of this lane's pixel + chunk from the run's first pixel
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
+    for (int i = 0; i < (LEAN ? 1 : A_PER); ++i) {
         const int q = (i * NW + wave) * 8 + lr;
         q_off[i] = (unsigned)(q * p.ld_in * 2 + jj * 16);
     }
+    const unsigned q_stride = (unsigned)(NW * 8 * p.ld_in) * 2u;
+    auto q_voff = [&](int i) __attribute__((always_inline)) -> unsigned {
+        if constexpr (LEAN) return q_off[0] + (unsigned)i * q_stride;
+        else return q_off[i];
+    };
     int lg_tile = first_tile, lg_cg = 0, lg_r = 0;
     bool lg_live = true;
     int lg_first = 0;                              // raster index of the run's first pixel (may be negative)
@@ -163,7 +178,7 @@ conv_v5_kernel(const ConvArgs p) {
         if (i * NW + wave >= A_PIECES) return;                                                  // wave-uniform
         const int q = (i * NW + wave) * 8 + lr;
         const bool ok = lg_live && (unsigned)(lg_first + q) < (unsigned)p.M && lg_cg * 8 + jj < p.C8;
-        MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_off[i] : kOOB, lg_soff);
+        MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_voff(i) : kOOB, lg_soff);
     };
     auto run_next = [&]() __attribute__((always_inline)) {
         if (++lg_r == 3) {
@@ -340,7 +355,7 @@ conv_v5_kernel(const ConvArgs p) {
         if (i * NW + wave < A_PIECES) {
             const int q = (i * NW + wave) * 8 + lr;
             const bool ok = (unsigned)(lg_first + q) < (unsigned)p.M && jj < p.C8;
-            MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, ok ? q_off[i] : kOOB, lg_soff);
+            MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, ok ? q_voff(i) : kOOB, lg_soff);
         }
     }
     run_next();
@@ -349,7 +364,7 @@ conv_v5_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             if ((B_PIECES % NW) != 0 && i == B_PER - 1 && wave >= B_PIECES % NW) continue;
-            MDHIP_DMA16(b_rsrc, smem + B_OFF + st * B_BYTES + (i * NW + wave) * 1024, b_off[i], l_step * 128);
+            MDHIP_DMA16(b_rsrc, smem + B_OFF + st * B_BYTES + (i * NW + wave) * 1024, b_voff(i), l_step * 128);
         }
         dma_b_done();
     }
@@ -395,7 +410,10 @@ conv_v5_kernel(const ConvArgs p) {
             //      fragment addresses of the next step are selected; MFMA chunk g = fragment column g ----
 #pragma unroll
             for (int g = 0; g < FN; ++g) {
-                wb[g] = read_w(cur, 1, g);
+                // LEAN: the weight fragment of the other k half goes into the registers the chunk before released (one
+                // spare fragment, read first): 6 weight fragments live instead of 10
+                if constexpr (LEAN) wb[(g + FN - 1) % FN] = read_w(cur, 1, (g + FN - 1) % FN);
+                else wb[g] = read_w(cur, 1, g);
                 if (g < FM) { xb[g] = read_x(g, 1); set_a_eff_one(nbuf, nr, ns, g); }
                 if (g == FN - 1) {
 #pragma unroll
@@ -420,7 +438,8 @@ conv_v5_kernel(const ConvArgs p) {
             //      pieces (weight slab of step+2; in steps 0 and 1 the next run) behind the MFMA chunks ----
 #pragma unroll
             for (int g = 0; g < FN; ++g) {
-                wa[g] = read_w(cur ^ 1, 0, g);
+                if constexpr (LEAN) wa[(g + FN - 1) % FN] = read_w(cur ^ 1, 0, (g + FN - 1) % FN);
+                else wa[g] = read_w(cur ^ 1, 0, g);
                 if (g < FM) xa[g] = read_x(g, 0);
                 if (g == FN - 1) {
 #pragma unroll
@@ -477,11 +496,13 @@ conv_v5_kernel(const ConvArgs p) {
     X(2, 256, 160, 4, 2, 0) \
     X(3, 192, 80, 4, 1, 0)  \
     X(4, 64, 160, 2, 2, 0)  \
-    X(5, 64, 80, 2, 1, 0)
+    X(5, 64, 80, 2, 1, 0)   \
+    X(6, 160, 320, 2, 4, 0) \
+    X(7, 320, 160, 4, 2, 0)
 #define MDHIP_CONV5_PROF(X)  \
-    X(6, 128, 160, 2, 2, 1)  \
-    X(7, 128, 160, 2, 2, 16) \
-    X(8, 128, 160, 2, 2, 22)
+    X(8, 128, 160, 2, 2, 1)  \
+    X(9, 128, 160, 2, 2, 16) \
+    X(10, 128, 160, 2, 2, 22)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
@@ -522,6 +543,9 @@ bool conv5_supports(int cfg, const ConvArgs& a) {
     const bool ok = a.wgt4 != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H &&
                     a.Wo == a.W && a.C8 >= 8 && (a.N % 8) == 0 &&
                     (long long)(2 * a.W + conv5_cfg(cfg).bm + 16) * a.ld_in * 2 + 4096 < 0x7fffffffLL;
+    if (ok && cfg < kNumMain5 && g_cfgs5[cfg].threads >= 512 && g_cfgs5[cfg].bm * g_cfgs5[cfg].bn == 160 * 320 &&
+        (a.n_rows % g_cfgs5[cfg].bn) != 0)
+        return false;                                     // the 80x80-wave-tile configurations (LEAN)
     if (ok && cfg >= kNumMain5 && cfg < first5c()) return conv5s_supports(cfg - kNumMain5, a);
     if (ok && cfg >= first5c() && cfg < conv5_num_cfgs()) return conv5c_supports(cfg - first5c(), a);
     return ok;

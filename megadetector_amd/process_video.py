@@ -254,10 +254,98 @@ def video_results_to_md_format(md_results):
     return out
 
 
+# --------------------------------------------------------------------------------------------
+# many videos on several GPUs (BASELINE.json configs[3]): shard the VIDEO list, one process per GPU, no collectives
+# --------------------------------------------------------------------------------------------
+def video_cost(what):
+    """what a video costs, for balancing: its frame count when the source says so, else its file size"""
+    n = getattr(what, 'n_frames', None)
+    if n is not None:
+        return int(n)
+    if isinstance(what, (list, tuple)):
+        return len(what)
+    try:
+        return int(os.path.getsize(what))
+    except Exception:
+        return 1
+
+
+def shard_videos(videos, n_shards, cost=video_cost):
+    """
+    Assigns whole videos to shards so that the summed cost is balanced: largest first, each to the lightest shard
+    (ties: lowest shard index) -- deterministic.  The reference's out-of-process recipe splits the extracted FRAME
+    list into equal chunks (notebooks/manage_video_batch.py:51-67 -> manage_local_batch.py:496); whole videos keep
+    the decode of a file and its frames' fixed shape on one GPU.  Returns [[index into videos, ...] per shard], each
+    in the original order.
+    """
+    order = sorted(range(len(videos)), key=lambda i: (-cost(videos[i][1]), i))
+    load = [0] * n_shards
+    shards = [[] for _ in range(n_shards)]
+    for i in order:
+        g = min(range(n_shards), key=lambda k: (load[k], k))
+        shards[g].append(i)
+        load[g] += max(1, cost(videos[i][1]))
+    return [sorted(sh) for sh in shards]
+
+
+def _video_shard_worker(gpu, model_file, videos, opts, run_kwargs, n_gpus, out_q):
+    try:
+        from . import placement
+        placement.pin_worker(gpu, n_gpus)
+        opts = dict(opts)
+        opts['device'] = 'cuda:{}'.format(gpu)
+        detector = run_detector.load_detector(model_file, detector_options=opts)
+        import gc
+        gc.collect()
+        gc.freeze()
+        out_q.put((gpu, run_detector_on_videos(detector, videos, **run_kwargs), None))
+    except Exception as e:
+        out_q.put((gpu, None, repr(e)))
+
+
+def merge_video_shards(videos, shards, shard_results):
+    """the per-shard returns of run_detector_on_videos back in the order of `videos`, with the duplicate / omission
+    checks of the image path's merge (reference notebooks/manage_local_batch.py:930-964)"""
+    n = len(videos)
+    slots = [None] * n
+    for idx, md in zip(shards, shard_results):
+        assert len(md['video_filenames']) == len(idx), 'a shard returned {} of its {} videos'.format(
+            len(md['video_filenames']), len(idx))
+        for k, i in enumerate(idx):
+            if slots[i] is not None:
+                raise ValueError('duplicate result for video {}'.format(videos[i][0]))
+            assert md['video_filenames'][k] == videos[i][0].replace('\\', '/')
+            slots[i] = (md['video_filenames'][k], md['frame_rates'][k], md['results'][k])
+    missing = [videos[i][0] for i in range(n) if slots[i] is None]
+    if missing:
+        raise ValueError('{} videos have no result (first: {})'.format(len(missing), missing[0]))
+    return {'video_filenames': [s_[0] for s_ in slots], 'frame_rates': [s_[1] for s_ in slots],
+            'results': [s_[2] for s_ in slots]}
+
+
+def run_detector_on_videos_sharded(model_file, videos, n_gpus, detector_options=None, worker=None, **run_kwargs):
+    """
+    run_detector_on_videos on n_gpus GPUs: whole videos are assigned to GPUs (shard_videos), every shard runs in a
+    spawned process with its own detector (device cuda:g) and CPU set (placement.py); the result equals the
+    one-process result.  `worker` replaces the shard process body in the CPU tests.
+    """
+    from .run_detector_batch import run_spawned_shards
+    shards = shard_videos(videos, n_gpus)
+    args = [(model_file, [videos[i] for i in shards[g]], dict(detector_options or {}), dict(run_kwargs), n_gpus)
+            for g in range(n_gpus)]
+    return merge_video_shards(videos, shards, run_spawned_shards(worker or _video_shard_worker, args, n_gpus))
+
+
 def process_videos(model_file, input_video_file, output_json_file=None, frame_sample=None, time_sample=None,
                    json_confidence_threshold=DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD, image_size=None, recursive=True,
-                   batch_size=8, detector_options=None, detector=None, exit_on_empty_video=False, verbose=False):
-    """reference process_video.py:123-272 (the options that touch this path)"""
+                   batch_size=8, detector_options=None, detector=None, exit_on_empty_video=False, verbose=False,
+                   n_gpus=1, videos=None, open_source=None, shard_worker=None):
+    """
+    reference process_video.py:123-272 (the options that touch this path).  n_gpus > 1 (BASELINE.json configs[3],
+    reference notebooks/manage_video_batch.py:51-67,201-218 does it out of process): the video list is sharded over
+    the GPUs of the node, the per-video JSON is the one-process one.  `videos` ([(relative name, source argument)]) and
+    `open_source` replace the folder scan and the cv2 decoder (tests, frames decoded elsewhere).
+    """
     if frame_sample is not None and time_sample is not None:
         raise ValueError('frame_sample and time_sample are mutually exclusive')
     if output_json_file is None:
@@ -266,26 +354,33 @@ def process_videos(model_file, input_video_file, output_json_file=None, frame_sa
         print('Output file not specified, defaulting to {}'.format(output_json_file))
     assert output_json_file.endswith('.json'), 'Illegal output file {}'.format(output_json_file)
     every = -1 * time_sample if time_sample is not None else frame_sample
-    if detector is None:
-        opts = dict(detector_options or {})
-        if batch_size > 1:
-            opts['batch_size'] = batch_size
-        if image_size is not None and int(image_size) > int(opts.get('max_image_size', 1280) or 1280):
-            opts['max_image_size'] = int(image_size)     # the device arena is planned at construction
-        detector = run_detector.load_detector(model_file, detector_options=opts)
-    import gc
-    gc.collect()
-    gc.freeze()              # see run_detector_batch.load_and_run_detector_batch
-    if os.path.isfile(input_video_file):
-        folder = os.path.dirname(input_video_file)
-        videos = [(os.path.basename(input_video_file), input_video_file)]
+    opts = dict(detector_options or {})
+    if batch_size > 1:
+        opts['batch_size'] = batch_size
+    if image_size is not None and int(image_size) > int(opts.get('max_image_size', 1280) or 1280):
+        opts['max_image_size'] = int(image_size)     # the device arena is planned at construction
+    if videos is None:
+        if os.path.isfile(input_video_file):
+            videos = [(os.path.basename(input_video_file), input_video_file)]
+        else:
+            assert os.path.isdir(input_video_file), '{} is neither a file nor a folder'.format(input_video_file)
+            folder = input_video_file
+            videos = [(os.path.relpath(f, folder).replace('\\', '/'), f) for f in find_videos(folder, recursive=recursive)]
+    run_kwargs = dict(every_n_frames=every, batch_size=batch_size, detection_threshold=json_confidence_threshold,
+                      image_size=image_size, error_on_empty_video=exit_on_empty_video, verbose=verbose)
+    if open_source is not None:
+        run_kwargs['open_source'] = open_source
+    if n_gpus > 1 and len(videos) > 1:
+        assert detector is None, 'a detector object cannot be shared between GPU processes: pass the model file'
+        md = run_detector_on_videos_sharded(model_file, videos, min(n_gpus, len(videos)), detector_options=opts,
+                                            worker=shard_worker, **run_kwargs)
     else:
-        assert os.path.isdir(input_video_file), '{} is neither a file nor a folder'.format(input_video_file)
-        folder = input_video_file
-        videos = [(os.path.relpath(f, folder).replace('\\', '/'), f) for f in find_videos(folder, recursive=recursive)]
-    md = run_detector_on_videos(detector, videos, every_n_frames=every, batch_size=batch_size,
-                                detection_threshold=json_confidence_threshold, image_size=image_size,
-                                error_on_empty_video=exit_on_empty_video, verbose=verbose)
+        if detector is None:
+            detector = run_detector.load_detector(model_file, detector_options=opts)
+        import gc
+        gc.collect()
+        gc.freeze()              # see run_detector_batch.load_and_run_detector_batch
+        md = run_detector_on_videos(detector, videos, **run_kwargs)
     print('Finished running MD on videos')
     images = video_results_to_md_format(md)
     run_detector_batch.write_results_to_file(images, output_json_file, relative_path_base=None, detector_file=model_file)

@@ -34,7 +34,7 @@ import threading
 import time
 from datetime import datetime
 
-from . import feed, run_detector
+from . import feed, placement, run_detector
 from .feed import load_image, EXIF_IMAGE_ROTATIONS          # noqa: F401  (re-exported)
 from .constants import FAILURE_IMAGE_OPEN, FAILURE_INFER, DEFAULT_OUTPUT_CONFIDENCE_THRESHOLD
 from .constants import DEFAULT_DETECTOR_LABEL_MAP
@@ -639,6 +639,12 @@ def shard_checkpoint_path(checkpoint_path, gpu):
 
 def _shard_worker(gpu, model_file, files, kwargs, out_q):
     try:
+        n_gpus = kwargs.pop('_n_gpus', 1)
+        # CPUs of this GPU's NUMA node, disjoint from the other shards'; the loader processes spawned below inherit
+        # the mask and are sized to it (placement.py)
+        cpus = placement.pin_worker(gpu, n_gpus)
+        if cpus and kwargs.get('use_image_queue'):
+            kwargs['loader_workers'] = placement.loader_workers_for(kwargs.get('loader_workers', default_loaders), len(cpus))
         opts = dict(kwargs.pop('detector_options', None) or {})
         opts['device'] = 'cuda:{}'.format(gpu)
         kwargs['checkpoint_path'] = shard_checkpoint_path(kwargs.get('checkpoint_path'), gpu)
@@ -648,19 +654,60 @@ def _shard_worker(gpu, model_file, files, kwargs, out_q):
         out_q.put((gpu, None, repr(e)))
 
 
+def run_spawned_shards(target, shard_args, n_shards):
+    """
+    One *spawned* process per shard (a forked child of a process that has touched HIP is undefined behaviour):
+    `target(g, *shard_args[g], out_q)` posts (g, result, error-or-None) on out_q.  Returns [result of shard 0, ...];
+    raises when a shard reports an error or dies without a result (its exit code is polled: a process killed by a
+    signal -- HIP fault, OOM killer -- never posts).  Shared by the image path (run_sharded) and the video path
+    (process_video.process_videos).
+    """
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out_q = ctx.Queue()
+    procs = []
+    for g in range(n_shards):
+        p = ctx.Process(target=target, args=(g,) + tuple(shard_args[g]) + (out_q,))
+        p.start()
+        procs.append(p)
+    got = {}
+    try:
+        while len(got) < n_shards:
+            try:
+                g, res, err = out_q.get(timeout=2.0)
+            except queue.Empty:
+                dead = [g for g, p in enumerate(procs) if g not in got and not p.is_alive()]
+                if dead and out_q.empty():
+                    time.sleep(0.5)                  # its last message may still be in the pipe
+                    if out_q.empty():
+                        raise RuntimeError('shard {} exited with code {} without a result'.format(
+                            dead[0], procs[dead[0]].exitcode))
+                continue
+            if err is not None:
+                raise RuntimeError('shard {} failed: {}'.format(g, err))
+            got[g] = res
+    except BaseException:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        raise
+    for p in procs:
+        p.join()
+    return [got[g] for g in range(n_shards)]
+
+
 def run_sharded(model_file, image_file_names, n_gpus, results=None, worker=None, **kwargs):
     """
     Runs load_and_run_detector_batch on n_gpus GPUs of one node: the image list is split
     `i % n_gpus`, each shard runs in its own *spawned* process pinned to one GPU
-    (detector_options['device'] = 'cuda:g', reference pytorch_detector.py:853-858), results are
-    merged on the host.  There is no inter-GPU traffic.
+    (detector_options['device'] = 'cuda:g', reference pytorch_detector.py:853-858) and to that GPU's share of the
+    CPUs (placement.py), results are merged on the host.  There is no inter-GPU traffic.
 
     Checkpoints: shard g writes `<checkpoint_path>.shard<g>` (shard_checkpoint_path).  `results` (restored from a
     checkpoint, single-GPU or merged from shard files by load_sharded_checkpoints) are kept as they are; only the
     files without a result are sharded, so a resumed run recomputes nothing.
     `worker` replaces _shard_worker in the CPU tests.
     """
-    import multiprocessing as mp
     files = _resolve_image_list(image_file_names)
     results = list(results) if results else []
     done = set(r['file'] for r in results)
@@ -682,39 +729,13 @@ def run_sharded(model_file, image_file_names, n_gpus, results=None, worker=None,
         # this run's first checkpoints (a resumed run is split i % n again): keep everything restored so far in the
         # plain file, which load_sharded_checkpoints unions with the shard files -- a second crash loses nothing.
         write_checkpoint(ck, results)
-    ctx = mp.get_context('spawn')
-    out_q = ctx.Queue()
     shards = shard_image_list(todo, n_gpus)
-    procs = []
-    for g in range(n_gpus):
-        p = ctx.Process(target=worker or _shard_worker, args=(g, model_file, shards[g], dict(kwargs), out_q))
-        p.start()
-        procs.append(p)
-    got = {}
-    try:
-        while len(got) < n_gpus:
-            try:
-                g, res, err = out_q.get(timeout=2.0)
-            except queue.Empty:
-                # a shard killed by a signal (HIP fault, OOM killer) never posts: notice its exit instead of waiting
-                dead = [g for g, p in enumerate(procs) if g not in got and not p.is_alive()]
-                if dead and out_q.empty():
-                    time.sleep(0.5)                  # its last message may still be in the pipe
-                    if out_q.empty():
-                        raise RuntimeError('shard {} exited with code {} without a result'.format(
-                            dead[0], procs[dead[0]].exitcode))
-                continue
-            if err is not None:
-                raise RuntimeError('shard {} failed: {}'.format(g, err))
-            got[g] = res
-    except BaseException:
-        for p in procs:
-            if p.is_alive():
-                p.terminate()
-        raise
-    for p in procs:
-        p.join()
-    return merge_shard_results([results] + [got[g] for g in range(n_gpus)], expected_files=files)
+    shard_kwargs = dict(kwargs)
+    if worker is None:
+        shard_kwargs['_n_gpus'] = n_gpus
+    got = run_spawned_shards(worker or _shard_worker, [(model_file, shards[g], dict(shard_kwargs)) for g in range(n_gpus)],
+                             n_gpus)
+    return merge_shard_results([results] + got, expected_files=files)
 
 
 def load_sharded_checkpoints(checkpoint_path, n_gpus):

@@ -349,3 +349,44 @@ def test_strip_and_fused_kernels_on_other_80_channel_blocks():
         print('width-0.625 P5 net, fused 80-channel blocks: worst layer error max {:.2e} mean {:.2e}'.format(*worst))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_eight_wave_tiles_are_bit_identical_to_the_row_segment_kernel(dtype):
+    """The one-workgroup-per-CU configurations (8 waves, 80x80 wave tiles: conv_v5<160,320> / <320,160> and the
+    role-split schedule of conv_v7.cpp) keep conv_v5's K order and the MFMA chain of every accumulator: the same bits
+    as conv_v5<128,160> on every 3x3 / stride-1 conv they take (N a multiple of their BN), for ragged tile counts
+    (maps that are no multiple of 160 / 320 pixels), half-full channel groups (C = 160: 64 + 64 + 32), with and
+    without the residual, several images per batch."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    from test_gpu_parity import EIGHT_WAVE_TILES
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    for (n, hh, ww) in ((2, 384, 640), (3, 192, 320), (1, 640, 640)):
+        ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+        try:
+            cfgs = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith(EIGHT_WAVE_TILES)]
+            assert len(cfgs) >= 2 and not any(ctx.cfg_is_bitwise(c) for c in cfgs)
+            classic = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == 'v5:run128x160/2x2/0'][0]
+            imgs = PU.random_images(n, hh, ww, seed=hh + 5 * ww)
+            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            convs = [o['op'] for o in ctx.op_infos() if o['kind'] == 0]
+            takers = {c: [op for op in convs if ctx.op_supports_cfg(op, c)] for c in cfgs}
+            every = sorted(set(op for ops in takers.values() for op in ops))
+            assert len(every) >= 30, len(every)                       # the bottleneck 3x3s of the 160- / 320- / 480- / 640-channel blocks
+            for op in every:
+                ctx.set_op_cfg(op, classic)
+            ctx.forward(n, hh, ww)
+            ref = ctx.read_predictions(n).copy()
+            for cfg in cfgs:
+                assert len(takers[cfg]) >= 12, (ctx.conv_cfg_name(cfg), len(takers[cfg]))
+                for op in every:
+                    ctx.set_op_cfg(op, cfg if op in takers[cfg] else classic)
+                ctx.forward(n, hh, ww)
+                ran = {ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['op'] in takers[cfg]}
+                assert ran == {ctx.conv_cfg_name(cfg)}
+                np.testing.assert_array_equal(ctx.read_predictions(n), ref, err_msg=ctx.conv_cfg_name(cfg))
+            for op in every:
+                ctx.set_op_cfg(op, -1)
+        finally:
+            ctx.close()

@@ -261,6 +261,11 @@ def test_tile_configurations_agree_bitwise(n6):
             ctx.set_op_cfg(op, -1)
 
 
+# one-workgroup-per-CU tiles with 80x80 wave tiles: they take layers whose channel count is a multiple of their BN only
+# (160 / 320: the x6 widths) and are covered on that topology by tests/test_gpu_headline.py
+EIGHT_WAVE_TILES = ('v5:run160x320', 'v5:run320x160', 'v7:')
+
+
 def test_row_patch_conv_matches_implicit_gemm_and_oracle():
     """
     The row-patch direct convolution (conv_v4.cpp) and the row-segment kernels (conv_v5.cpp), each on
@@ -282,7 +287,7 @@ def test_row_patch_conv_matches_implicit_gemm_and_oracle():
         # (the e4m3 family f8:* takes fp8 operands only: tests/test_gpu_fp8.py; the strip kernel v5:strip* takes the
         # 80 -> 80 channel layers of the x6 stack only: tests/test_gpu_headline.py)
         patch_cfgs = [c for c in range(ctx.num_conv_cfgs())
-                      if not ctx.cfg_is_bitwise(c) and not ctx.conv_cfg_name(c).startswith(('f8:', 'v5:strip'))]
+                      if not ctx.cfg_is_bitwise(c) and not ctx.conv_cfg_name(c).startswith(('f8:', 'v5:strip') + EIGHT_WAVE_TILES)]
         assert patch_cfgs, 'no row-patch configuration in this build'
         x, _ = PU.oracle_input(imgs, WW, 64)
         assert tuple(x.shape[2:]) == (HH, WW)

@@ -177,3 +177,80 @@ def test_opencv_source_protocol_with_a_stand_in_cv2(tmp_path, monkeypatch):
     got_dets = sorted((d['frame_number'], d['conf'], tuple(d['bbox'])) for d in images[0]['detections'])
     ref_dets = sorted((int(r['file'][5:11]), d['conf'], tuple(d['bbox'])) for r in ref['results'] for d in (r.get('detections') or []))
     assert got_dets == ref_dets and len(got_dets) > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3]: videos across the GPUs of a node (reference notebooks/manage_video_batch.py:51-67,201-218)
+# ---------------------------------------------------------------------------------------------------------------------
+def _open_array(what):
+    if what is None:
+        raise RuntimeError('cannot open')
+    return PV.ArrayFrameSource(what['frames'], frame_rate=what['fps'])
+
+
+def _stub_video_shard_worker(gpu, model_file, videos, opts, run_kwargs, n_gpus, out_q):
+    """stands in for the GPU process of one shard: same driver code, stub detector; reports which device it was given"""
+    try:
+        md = PV.run_detector_on_videos(PipelinedStub(), videos, **run_kwargs)
+        md['_gpu'] = gpu
+        out_q.put((gpu, md, None))
+    except Exception as e:
+        out_q.put((gpu, None, repr(e)))
+
+
+def _video_set():
+    lens = [9, 3, 14, 5, 1, 7, 11]
+    vids = [('cam{}/clip{}.mp4'.format(i % 3, i), {'frames': _frames(n, seed=10 + i), 'fps': 10.0 + i})
+            for i, n in enumerate(lens)]
+    vids.insert(4, ('cam1/broken.mp4', None))
+    return vids
+
+
+def test_video_sharding_is_balanced_and_deterministic():
+    vids = _video_set()
+    cost = lambda w: 1 if w is None else len(w['frames'])          # noqa: E731
+    for g in (2, 3, 8):
+        shards = PV.shard_videos(vids, g, cost=cost)
+        assert sorted(i for sh in shards for i in sh) == list(range(len(vids)))         # every video exactly once
+        assert shards == PV.shard_videos(vids, g, cost=cost)
+        loads = [sum(cost(vids[i][1]) for i in sh) for sh in shards]
+        assert max(loads) - min(l for l in loads if l) <= max(cost(v[1]) for v in vids)  # LPT bound
+    two = PV.shard_videos(vids, 2, cost=cost)
+    loads = [sum(cost(vids[i][1]) for i in sh) for sh in two]
+    assert abs(loads[0] - loads[1]) <= 1                                                   # 51 frames: 25 / 26
+    # default cost: frame count of in-memory lists, file size for paths
+    assert PV.video_cost([1, 2, 3]) == 3 and PV.video_cost('/nonexistent/file.mp4') == 1
+
+
+def test_videos_across_two_gpu_processes_equal_the_one_process_output(tmp_path):
+    """world 2, spawned shard processes (stub detector): the merged per-video JSON is byte-identical to the
+    one-process run, a video that cannot be opened fails alone, a dead shard is noticed"""
+    vids = _video_set()
+    one = str(tmp_path / 'one.json')
+    two = str(tmp_path / 'two.json')
+    kw = dict(frame_sample=2, batch_size=4, videos=vids, open_source=_open_array, json_confidence_threshold=0.0)
+    im1 = PV.process_videos('md_v5a.0.0.pt', 'unused', one, detector=PipelinedStub(), **kw)
+    im2 = PV.process_videos('md_v5a.0.0.pt', 'unused', two, n_gpus=2, shard_worker=_stub_video_shard_worker, **kw)
+    assert json.loads(json.dumps(im1)) == json.loads(json.dumps(im2))
+    strip = lambda p: __import__('re').sub(r'"detection_completion_time": "[^"]*"', '', open(p).read())   # noqa: E731
+    assert strip(one) == strip(two)
+    assert [im['file'] for im in im2] == [v[0] for v in vids]
+    broken = [im for im in im2 if im['file'] == 'cam1/broken.mp4'][0]
+    assert broken['detections'] is None and 'Failure processing video' in broken['failure']
+    # more GPUs than videos: never an empty shard process
+    im3 = PV.process_videos('md_v5a.0.0.pt', 'unused', str(tmp_path / 'three.json'), n_gpus=16,
+                            shard_worker=_stub_video_shard_worker, **kw)
+    assert json.loads(json.dumps(im3)) == json.loads(json.dumps(im1))
+
+
+def _dying_video_worker(gpu, model_file, videos, opts, run_kwargs, n_gpus, out_q):
+    if gpu == 1:
+        os._exit(3)
+    _stub_video_shard_worker(gpu, model_file, videos, opts, run_kwargs, n_gpus, out_q)
+
+
+def test_dead_video_shard_raises(tmp_path):
+    vids = _video_set()
+    with pytest.raises(RuntimeError, match='exited with code 3'):
+        PV.process_videos('md_v5a.0.0.pt', 'unused', str(tmp_path / 'x.json'), n_gpus=2, videos=vids,
+                          open_source=_open_array, shard_worker=_dying_video_worker, batch_size=4)
