@@ -502,7 +502,11 @@ conv_v5_kernel(const ConvArgs p) {
 #define MDHIP_CONV5_PROF(X)  \
     X(8, 128, 160, 2, 2, 1)  \
     X(9, 128, 160, 2, 2, 16) \
-    X(10, 128, 160, 2, 2, 22)
+    X(10, 128, 160, 2, 2, 22) \
+    X(11, 320, 160, 4, 2, 1) \
+    X(12, 320, 160, 4, 2, 16) \
+    X(13, 320, 160, 4, 2, 6) \
+    X(14, 320, 160, 4, 2, 22)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
@@ -511,7 +515,7 @@ static const ConvCfg g_cfgs5[] = {
     MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
 #undef X
 };
-constexpr int kNumProf5 = 3;
+constexpr int kNumProf5 = 7;
 
 // ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp and the C = 80
 // strip kernel of conv_v5c.cpp (same K order, same results), then the developer variants

@@ -8,8 +8,10 @@ export TMPDIR=/tmp
 TAG="$1"; shift
 R="$PWD"
 i=0
-for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA SQ_INSTS_SALU"; do
+# (GRBM_GUI_ACTIVE rides along in both passes: GRBM slots are independent of the 8 SQ slots; it gives the shader clock
+#  the kernel actually ran at = GRBM_GUI_ACTIVE / kernel duration, MI355X_MICROARCH.md "DVFS give-back")
+for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA SQ_INSTS_SALU GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   (cd /tmp && timeout 600 rocprofv3 --pmc $SET -d /tmp/pmc_${TAG}_$i -o p --output-format csv -- \
      python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --lean "$@" > "$R/gpurun_out/pmc_${TAG}_$i.log" 2>&1)
@@ -17,22 +19,44 @@ done
 python - "$TAG" > "gpurun_out/pmc_${TAG}.txt" <<'PY'
 import collections, csv, glob, re, sys
 tag = sys.argv[1]
+N_SIMD = 256 * 4                 # MI355X: 256 CUs x 4 SIMDs
+MFMA_CYCLES = 16.0               # v_mfma_f32_16x16x32_{bf16,f16}: 16384 FLOP at 1024 FLOP / clk / SIMD (2.5 PFLOP/s at 2.4 GHz);
+                                 # the block-scaled fp8 K = 128 instruction does 65536 FLOP in 32 cycles
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+seen = set()
 for f in glob.glob('/tmp/pmc_%s_*/**/*counter_collection.csv' % tag, recursive=True):
     for row in csv.DictReader(open(f)):
         name = re.sub(r'\(.*', '', row.get('Kernel_Name', ''))
         acc[name][row['Counter_Name']].append(float(row['Counter_Value']))
+        key = (f, row.get('Dispatch_Id'))
+        if key not in seen and row.get('Start_Timestamp') and row.get('End_Timestamp'):
+            seen.add(key)
+            dur[name].append(float(row['End_Timestamp']) - float(row['Start_Timestamp']))
 for name in sorted(acc, key=lambda n: -sum(acc[n].get('SQ_BUSY_CYCLES', [0]))):
     c = {k: sum(v) / len(v) for k, v in acc[name].items()}
     n = len(next(iter(acc[name].values())))
-    print('%s   (%d dispatches; per-dispatch means)' % (name, n))
+    d_ns = sum(dur[name]) / len(dur[name]) if dur[name] else 0.0
+    print('%s   (%d dispatches; per-dispatch means; %.1f us per dispatch under the counter passes)' % (name, n, d_ns / 1e3))
     for k in sorted(c):
         print('    %-28s %.6g' % (k, c[k]))
     w = c.get('SQ_WAVE_CYCLES')
     if w:
-        print('    -> wait %.1f %%, issue-stall %.1f %%, LDS-issue-stall %.1f %%, active %.1f %% of wave cycles; MFMA busy %.1f %% of SQ busy x4'
+        print('    -> wait %.1f %%, issue-stall %.1f %%, LDS-issue-stall %.1f %%, active %.1f %% of wave cycles'
               % (100 * c.get('SQ_WAIT_ANY', 0) / w, 100 * c.get('SQ_WAIT_INST_ANY', 0) / w, 100 * c.get('SQ_WAIT_INST_LDS', 0) / w,
-                 100 * c.get('SQ_ACTIVE_INST_ANY', 0) / w, 100 * c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1.0, 4 * c.get('SQ_BUSY_CYCLES', 1))))
+                 100 * c.get('SQ_ACTIVE_INST_ANY', 0) / w))
+    if c.get('SQ_INSTS_MFMA') and d_ns > 0:
+        # MFMA-pipe utilisation = matrix instructions x cycles each / (SIMDs x kernel cycles), kernel cycles from the
+        # measured shader clock of the dispatch (GRBM_GUI_ACTIVE / duration); and against the 2.4 GHz the vendor peak
+        # assumes (= achieved / peak FLOP/s for 16-bit launches)
+        clk = c.get('GRBM_GUI_ACTIVE', 0.0) / d_ns if c.get('GRBM_GUI_ACTIVE') else 0.0
+        per = 2.0 if 'f8' in name else 1.0
+        busy = c['SQ_INSTS_MFMA'] * MFMA_CYCLES * per
+        if clk > 0:
+            print('    -> shader clock %.2f GHz; MFMA-pipe utilisation %.3f of the cycles the kernel ran (%.3f against 2.4 GHz)'
+                  % (clk, busy / (N_SIMD * d_ns * clk), busy / (N_SIMD * d_ns * 2.4)))
+        else:
+            print('    -> MFMA-pipe utilisation %.3f against 2.4 GHz (no clock counter in this pass)' % (busy / (N_SIMD * d_ns * 2.4)))
     if c.get('SQ_INSTS_MFMA'):
         print('    -> per MFMA: VALU %.2f, LDS %.2f, VMEM %.3f, SALU %.2f; LDS bank-conflict cycles / LDS active cycles %.3f'
               % (c.get('SQ_INSTS_VALU', 0) / c['SQ_INSTS_MFMA'], c.get('SQ_INSTS_LDS', 0) / c['SQ_INSTS_MFMA'],
