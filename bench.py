@@ -387,6 +387,27 @@ def main():
                 e[1] += t
                 e[2] += o['flops']
             top = max(by_cfg.items(), key=lambda kv: kv[1][1])
+
+            def pmc_row(cfg_name):
+                """MFMA-pipe utilisation and shader clock of this kernel instantiation from the newest committed counter
+                summary (tools/pmc_bench.sh -> profiles/r*_pmc_bench_kernels.json); None when there is none"""
+                import glob
+                import re
+                m = re.match(r'(v2|v5:run|v5:strip|v7:cont|f8:run)?:?(\d+)x(\d+)/(\d+)x(\d+)', cfg_name)
+                if not m:
+                    return None
+                sym = {'v2': 'conv_v2_kernel', 'v5:run': 'conv_v5_kernel', 'f8:run': 'conv_f8_kernel'}.get(m.group(1))
+                if sym is None:
+                    return None
+                want = '{}<{}, {}, {}, {}'.format(sym, *m.groups()[1:])
+                for ppath in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_bench_kernels.json')), reverse=True):
+                    try:
+                        for kname, row in json.load(open(ppath)).get('kernels', {}).items():
+                            if want in kname:
+                                return dict(row, source='profiles/' + os.path.basename(ppath))
+                    except Exception:
+                        pass
+                return None
             roof['dominant_kernel'] = {
                 'name': ctx.conv_cfg_name(top[0]), 'launches_per_step': top[1][0],
                 'ms_per_step': round(top[1][1], 3), 'avg_launch_us': round(top[1][1] / top[1][0] * 1e3, 2),
@@ -394,6 +415,17 @@ def main():
                 'peak': PEAK_FP8_TFLOPS if ctx.conv_cfg_name(top[0]).startswith('f8:') else PEAK_BF16_TFLOPS,
                 'frac': round(top[1][2] / (top[1][1] * 1e-3) / 1e12 /
                               (PEAK_FP8_TFLOPS if ctx.conv_cfg_name(top[0]).startswith('f8:') else PEAK_BF16_TFLOPS), 4)}
+            # `frac` above IS the MFMA-pipe utilisation against the 2.4 GHz the vendor peak assumes (live events); the
+            # counter summary adds the utilisation against the clock the kernel really ran at
+            roof['dominant_kernel']['mfma_util'] = roof['dominant_kernel']['frac']
+            roof['dominant_kernel']['pmc'] = pmc_row(ctx.conv_cfg_name(top[0]))
+            # the most matrix-bound instantiation: highest FLOP rate among those with >= 5 % of the conv time
+            heavy = [kv for kv in by_cfg.items() if kv[1][1] >= 0.05 * conv_ms]
+            best = max(heavy, key=lambda kv: kv[1][2] / kv[1][1])
+            roof['fastest_heavy_kernel'] = {
+                'name': ctx.conv_cfg_name(best[0]), 'launches_per_step': best[1][0], 'ms_per_step': round(best[1][1], 3),
+                'achieved_tflops': round(best[1][2] / (best[1][1] * 1e-3) / 1e12, 2),
+                'mfma_util': round(best[1][2] / (best[1][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), 'pmc': pmc_row(ctx.conv_cfg_name(best[0]))}
         # per-stage HBM rooflines (north_star: "rocprof HBM GB/s for preprocess/NMS"): algorithmic bytes of SURVEY.md
         # section 8(d) / duration of the stage's kernels measured live (HIP events on the stream the stage is launched
         # on, timed region; the NMS pair also covers the D2H of the <= 300 x 6 results) -- decode from the per-op events

@@ -155,8 +155,21 @@ conv_igemm_kernel(const ConvArgs p) {
     int l_kt = KT, l_tile = first_tile - tile_step;
     const int kh = p.ntaps / p.kw;
 
+    // 1x1 / stride 1 / no padding: output pixel m is input pixel m -- no divisions, one mask bit (see conv_v2.cpp)
+    const bool pointwise = p.ntaps == 1 && p.stride == 1 && p.pad == 0 && p.H == p.Ho && p.W == p.Wo && p.C8 >= 8;
     auto init_loader_tile = [&](int tile_m) {
         const int m0 = tile_m * BM;
+        if (pointwise) {                                                            // wave-uniform
+            a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long long)m0 * p.ld_in), 0, kNumRecords, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int row = (i * NW + wave) * 8 + lr;
+                a_off[i] = (unsigned)(row * p.ld_in * 2);
+                a_mask[i] = (m0 + row < p.M) ? 1u : 0u;
+            }
+            c8 = jj; tap = 0; tr = 0; ts = 0;            // (C8 >= 8: the lane's first chunk is inside tap 0)
+            return;
+        }
         // descriptor based at the tile's first pixel minus the conv padding: every in-range tap
         // of every row of the tile has a small non-negative byte offset
         const int b0 = m0 / p.HoWo;
@@ -483,7 +496,6 @@ const Family g_fams[] = {
     {conv5_num_cfgs, conv5_cfg, conv5_supports, conv5_launch, conv5_init, false, -301, false, false},
     {conv6_num_cfgs, conv6_cfg, conv6_supports, conv6_launch, conv6_init, true, -401, false, false},     // the stem kernel: same K order
     {conv8_num_cfgs, conv8_cfg, conv8_supports, conv8_launch, conv8_init, false, -801, true, false},
-    {conv7_num_cfgs, conv7_cfg, conv7_supports, conv7_launch, conv7_init, false, -701, false, false},   // conv_v5's K order
 };
 constexpr int kNumFams = (int)(sizeof(g_fams) / sizeof(g_fams[0]));
 // family and local id of a global id >= kNumV1

@@ -67,7 +67,8 @@ constexpr int v2_waves_per_simd(int bm, int bn, int nw) {
 // wave and written to p.dbg); used by tools/convbench.cpp, never by the product path
 // UP = the variant that reads the first K slabs of a 1x1 conv from a low-resolution tensor (nearest-neighbour upsample in
 // place, ConvArgs::in_up); its own instantiation so that the loader of every other launch stays as it was
-template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false>
+// PW = the instantiation for 1x1 / stride 1 / unpadded convs (tile set-up without divisions, see init_tile)
+template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false, bool PW = false>
 __global__ void __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BM, BN, WM * WN))
 conv_v2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -135,7 +136,24 @@ conv_v2_kernel(const ConvArgs p) {
     const unsigned wrap_c = (unsigned)(p.ld_in * 2 - p.C8 * 16);        // next tap, same row
     const unsigned wrap_r = (unsigned)((p.W - p.kw) * p.ld_in * 2);     // first tap of the next kernel row
 
+    // 1x1 / stride 1 / no padding (most launches of this kernel, with 3 .. 10 slabs per tile): output pixel m IS input
+    // pixel m, so a lane's offset from the tile's first pixel never changes and the only mask bit is "m < M".  The
+    // general path below costs two integer divisions and a 9-tap mask per row -- ~5 000 cycles per tile and wave, a
+    // fifth of the whole 1x1 launch at K = 160 .. 320 (profiles/r3_convbench_v2_ablation.txt: "advance").
+    // (its own instantiation -- conv2_launch picks it -- so that the 3x3 / strided launches keep the code they had)
     auto init_tile = [&](int tile_m) __attribute__((always_inline)) {
+        if constexpr (PW) {
+            const int m0 = tile_m * BM;
+            a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long long)m0 * p.ld_in), 0, kNumRecords, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int row = (i * NW + wave) * 8 + lr;
+                a_off[i] = (unsigned)(row * p.ld_in * 2);
+                a_mask[i] = (m0 + row < p.M) ? 1u : 0u;
+            }
+            c8 = jj; ts = 0; tapbit = 1; tapoff = (unsigned)jj * 16u;
+            return;
+        }
         const int m0 = tile_m * BM;
         const int b0 = m0 / p.HoWo;
         const int rem0 = m0 - b0 * p.HoWo;
@@ -255,6 +273,10 @@ conv_v2_kernel(const ConvArgs p) {
         const int nbase = n0 + wn * TN + q4 * 4;
         // bias of all fragment columns first (scalar loads), then pixel-row by pixel-row so that the
         // stores that complete one cache line are issued back to back
+        // bias of all fragment columns first (scalar loads), then pixel-row by pixel-row so that the
+        // stores that complete one cache line are issued back to back
+        // (round 3, measured and not kept: the five columns as vector loads issued together -- the compiler's vmcnt wait
+        // for them also waits for the LDS-DMA pieces of the next tile that are in flight: epilogue + 25 .. 45 %)
         float bv[FN][4];
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -524,6 +546,9 @@ hipError_t conv2_init() {
 #define X(id, bm, bn, wm, wn)                                                                        \
     if (e == hipSuccess)                                                                           \
         e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes); \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, true>,          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
     MDHIP_CONV2_CFGS(X)
 #undef X
@@ -561,10 +586,13 @@ hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((conv_v2_kernel<160, 160, 2, 2, 0, true>), grid, dim3(256), c.lds_bytes, s, p);
         return hipGetLastError();
     }
+    // 1x1 / stride 1 / unpadded: the instantiation whose tile set-up needs no divisions (same loads, same results)
+    const bool pw = a.ntaps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
     switch (cfg) {
 #define X(id, bm, bn, wm, wn)                                                                        \
     case id:                                                                                       \
-        hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        if (pw) hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, true>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        else hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         break;
         MDHIP_CONV2_CFGS(X)
 #undef X

@@ -258,8 +258,12 @@ conv_v5_kernel(const ConvArgs p) {
         // brought back to the accumulator layout by the inverse of the store exchange (v_permlane16_swap, then
         // v_permlane32_swap: both are involutions).
         constexpr int NPAIR = FN / 2;
-        uint4 rpair[2][NPAIR > 0 ? NPAIR : 1];
-        uint2 rlast[2];
+        // residual rows in flight ahead of the row being finished: 1 (two workgroups per CU: the partner workgroup's
+        // MFMAs cover the round trip) or 2 (LEAN = one 8-wave workgroup per CU: every wave of the CU is in its epilogue
+        // at the same time, and each pixel row would otherwise wait out most of an HBM round trip on its own)
+        constexpr int RA = LEAN ? 2 : 1, RS = RA + 1;
+        uint4 rpair[RS][NPAIR > 0 ? NPAIR : 1];
+        uint2 rlast[RS];
         auto fetch_res_row = [&](int i, uint4 (&rp)[NPAIR > 0 ? NPAIR : 1], uint2& rl) {
             // branch-free (clamped) addresses: a load under a divergent branch would make the compiler
             // fall back from counted vmcnt waits to vmcnt(0), which also waits for stores
@@ -270,11 +274,14 @@ conv_v5_kernel(const ConvArgs p) {
                 rp[jp] = *(const uint4*)(rrow_p + min(n0 + wn * TN + jp * 32 + q4 * 8, p.N - 8));
             if (FN & 1) rl = *(const uint2*)(rrow_p + min(nbase + (FN - 1) * 16, p.N - 4));
         };
-        if constexpr (HAS_RES) fetch_res_row(0, rpair[0], rlast[0]);
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int a = 0; a < RA && a < FM; ++a) fetch_res_row(a, rpair[a % RS], rlast[a % RS]);
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             if constexpr (HAS_RES) {
-                if (i + 1 < FM) fetch_res_row(i + 1, rpair[(i + 1) & 1], rlast[(i + 1) & 1]);
+                if (i + RA < FM) fetch_res_row(i + RA, rpair[(i + RA) % RS], rlast[(i + RA) % RS]);
             }
             const int m = m0 + i * 16;
             float v[FN][4];
@@ -297,7 +304,7 @@ conv_v5_kernel(const ConvArgs p) {
                 };
 #pragma unroll
                 for (int jp = 0; jp < NPAIR; ++jp) {
-                    const uint4 d = rpair[i & 1][jp];            // as stored: (t0[0], t1[0], t0[1], t1[1])
+                    const uint4 d = rpair[i % RS][jp];           // as stored: (t0[0], t1[0], t0[1], t1[1])
                     auto s0 = __builtin_amdgcn_permlane16_swap(d.x, d.z, false, false);
                     auto s1 = __builtin_amdgcn_permlane16_swap(d.y, d.w, false, false);
                     auto a0 = __builtin_amdgcn_permlane32_swap(s0[0], s0[1], false, false);     // (a0, b0)
@@ -305,7 +312,7 @@ conv_v5_kernel(const ConvArgs p) {
                     add4(2 * jp, a0[0], a1[0]);
                     add4(2 * jp + 1, a0[1], a1[1]);
                 }
-                if (FN & 1) add4(FN - 1, rlast[i & 1].x, rlast[i & 1].y);
+                if (FN & 1) add4(FN - 1, rlast[i % RS].x, rlast[i % RS].y);
             }
             if constexpr ((PROF & 2) != 0) {
 #pragma unroll

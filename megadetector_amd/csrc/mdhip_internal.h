@@ -191,8 +191,6 @@ struct ConvCfg {
 //   conv5_* : 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp); its configurations
 //             for small launches (conv5s_*, conv_v5s.cpp) are listed behind its own
 //   conv6_* : the stem (3x3 over 16-channel space-to-depth pixels, N = 80) with its weights in registers (conv_v6.cpp)
-//   conv7_* : conv_v5's convolution under a role-split schedule: one 8-wave workgroup per CU, 80x80 wave tiles, the two
-//             waves of a SIMD alternate between a matrix phase and a memory phase (conv_v7.cpp); same results as conv5_*
 //   conv8_* : conv_v5's structure on e4m3 operands with the block-scaled K = 128 MFMA (conv_f8.cpp)
 // conv_launch returns hipSuccess or the launch error; conv_init raises the dynamic-LDS limits (one-off);
 // conv_cfg_is_bitwise_family is false for kernels whose result equals the others' up to fp32 summation
@@ -235,11 +233,6 @@ struct ConvCfg {
     bool conv6_supports(int cfg, const ConvArgs& a); \
     hipError_t conv6_launch(int cfg, const ConvArgs& a, hipStream_t s); \
     hipError_t conv6_init(); \
-    int conv7_num_cfgs(); \
-    const ConvCfg& conv7_cfg(int i); \
-    bool conv7_supports(int cfg, const ConvArgs& a); \
-    hipError_t conv7_launch(int cfg, const ConvArgs& a, hipStream_t s); \
-    hipError_t conv7_init(); \
     int conv8_num_cfgs(); \
     const ConvCfg& conv8_cfg(int i); \
     bool conv8_supports(int cfg, const ConvArgs& a); \

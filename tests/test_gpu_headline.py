@@ -353,8 +353,8 @@ def test_strip_and_fused_kernels_on_other_80_channel_blocks():
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_eight_wave_tiles_are_bit_identical_to_the_row_segment_kernel(dtype):
-    """The one-workgroup-per-CU configurations (8 waves, 80x80 wave tiles: conv_v5<160,320> / <320,160> and the
-    role-split schedule of conv_v7.cpp) keep conv_v5's K order and the MFMA chain of every accumulator: the same bits
+    """The one-workgroup-per-CU configurations (8 waves, 80x80 wave tiles: conv_v5<160,320> / <320,160>) keep
+    conv_v5's K order and the MFMA chain of every accumulator: the same bits
     as conv_v5<128,160> on every 3x3 / stride-1 conv they take (N a multiple of their BN), for ragged tile counts
     (maps that are no multiple of 160 / 320 pixels), half-full channel groups (C = 160: 64 + 64 + 32), with and
     without the residual, several images per batch."""

@@ -263,7 +263,7 @@ def test_tile_configurations_agree_bitwise(n6):
 
 # one-workgroup-per-CU tiles with 80x80 wave tiles: they take layers whose channel count is a multiple of their BN only
 # (160 / 320: the x6 widths) and are covered on that topology by tests/test_gpu_headline.py
-EIGHT_WAVE_TILES = ('v5:run160x320', 'v5:run320x160', 'v7:')
+EIGHT_WAVE_TILES = ('v5:run160x320', 'v5:run320x160')
 
 
 def test_row_patch_conv_matches_implicit_gemm_and_oracle():

@@ -126,7 +126,6 @@ int main(int argc, char** argv) {
         if (argv[i][0] == 't') { cfgs.push_back(-301 - atoi(argv[i] + 1)); continue; } // t0..: v5 developer variants
         if (argv[i][0] == 'u') { cfgs.push_back(-401 - atoi(argv[i] + 1)); continue; } // u0..: v6 developer variants
         if (argv[i][0] == 'f') { cfgs.push_back(-801 - atoi(argv[i] + 1)); continue; } // f0..: fp8 developer variants
-        if (argv[i][0] == 's') { cfgs.push_back(-701 - atoi(argv[i] + 1)); continue; } // s0..: conv_v7 (role-split) developer variants
         if (argv[i][0] == 'n') {                                                        // n<prefix>: every configuration whose name starts with prefix
             for (int j = 0; j < conv_num_cfgs(); ++j) if (!strncmp(conv_cfg(j).name, argv[i] + 1, strlen(argv[i] + 1))) cfgs.push_back(j);
             continue;
@@ -294,7 +293,7 @@ int main(int argc, char** argv) {
             if (ms < best) best = ms;
         }
         printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
-               cfg <= -801 ? conv8_cfg(conv8_num_cfgs() - 801 - cfg).name : cfg <= -701 ? conv7_cfg(conv7_num_cfgs() - 701 - cfg).name : cfg <= -401 ? conv6_cfg(conv6_num_cfgs() - 401 - cfg).name : cfg <= -301 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
+               cfg <= -801 ? conv8_cfg(conv8_num_cfgs() - 801 - cfg).name : cfg <= -401 ? conv6_cfg(conv6_num_cfgs() - 401 - cfg).name : cfg <= -301 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
                bad ? "  <-- MISMATCH" : "");
         if (cfg < 0) {
             // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
@@ -323,9 +322,7 @@ int main(int argc, char** argv) {
             }
             static const char* nm5[6] = {"half1 (reads Y + mfma X)", "waitcnt vmcnt/lgkmcnt", "barrier", "half2 (dma + reads X + mfma Y)",
                                          "advance", "epilogue (amortised)"};
-            static const char* nm7[6] = {"L phases (reads + dma issue)", "lgkmcnt + barrier after L", "M phases (mfma)", "vmcnt + barrier after M",
-                                         "epilogue + masks (amortised)", "-"};
-            const char* const* nm = (cfg <= -701 && cfg > -801) ? nm7 : nm5;
+            const char* const* nm = nm5;
             double tot = 0;
             for (int k = 0; k < 6; ++k) tot += sum[k];
             printf("    %d waves, %.0f steps each; cycles per step: total %.0f\n", waves, steps / waves, tot / steps);

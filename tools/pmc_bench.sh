@@ -33,6 +33,7 @@ for f in glob.glob('/tmp/pmc_%s_*/**/*counter_collection.csv' % tag, recursive=T
         if key not in seen and row.get('Start_Timestamp') and row.get('End_Timestamp'):
             seen.add(key)
             dur[name].append(float(row['End_Timestamp']) - float(row['Start_Timestamp']))
+summary = {}
 for name in sorted(acc, key=lambda n: -sum(acc[n].get('SQ_BUSY_CYCLES', [0]))):
     c = {k: sum(v) / len(v) for k, v in acc[name].items()}
     n = len(next(iter(acc[name].values())))
@@ -52,6 +53,9 @@ for name in sorted(acc, key=lambda n: -sum(acc[n].get('SQ_BUSY_CYCLES', [0]))):
         clk = c.get('GRBM_GUI_ACTIVE', 0.0) / d_ns if c.get('GRBM_GUI_ACTIVE') else 0.0
         per = 2.0 if 'f8' in name else 1.0
         busy = c['SQ_INSTS_MFMA'] * MFMA_CYCLES * per
+        summary[name] = {'dispatch_us': d_ns / 1e3, 'shader_clock_ghz': clk or None,
+                         'mfma_util_measured_clock': busy / (N_SIMD * d_ns * clk) if clk > 0 else None,
+                         'mfma_util_2p4ghz': busy / (N_SIMD * d_ns * 2.4)}
         if clk > 0:
             print('    -> shader clock %.2f GHz; MFMA-pipe utilisation %.3f of the cycles the kernel ran (%.3f against 2.4 GHz)'
                   % (clk, busy / (N_SIMD * d_ns * clk), busy / (N_SIMD * d_ns * 2.4)))
@@ -62,6 +66,9 @@ for name in sorted(acc, key=lambda n: -sum(acc[n].get('SQ_BUSY_CYCLES', [0]))):
               % (c.get('SQ_INSTS_VALU', 0) / c['SQ_INSTS_MFMA'], c.get('SQ_INSTS_LDS', 0) / c['SQ_INSTS_MFMA'],
                  c.get('SQ_INSTS_VMEM', 0) / c['SQ_INSTS_MFMA'], c.get('SQ_INSTS_SALU', 0) / c['SQ_INSTS_MFMA'],
                  c.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, c.get('SQ_LDS_IDX_ACTIVE', 1))))
+import json
+json.dump({'kernels': summary, 'note': 'tools/pmc_bench.sh: per-dispatch means of two rocprofv3 --pmc passes (counters only); MFMA-pipe utilisation = SQ_INSTS_MFMA x 16 cycles / (1024 SIMDs x dispatch time x clock)'},
+          open('gpurun_out/pmc_%s.json' % tag, 'w'), indent=1)
 PY
 rm -rf /tmp/pmc_${TAG}_*
 head -60 "gpurun_out/pmc_${TAG}.txt"
