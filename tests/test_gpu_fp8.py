@@ -119,10 +119,14 @@ def test_fp8_batch_invariance_and_saved_scales(s6_fp8):
         other.close()
 
 
-def test_fp8_headline_topology_layers():
-    """the MDv5a topology (x6 widths: channel groups 80 / 128+32 / 2*128+64 / 3*128+96 / 5*128) in fp8 mode"""
+@pytest.mark.parametrize('forced_batch', [None, 64])
+def test_fp8_headline_topology_layers(forced_batch):
+    """the MDv5a topology (x6 widths: channel groups 80 / 128+32 / 2*128+64 / 3*128+96 / 5*128) in fp8 mode -- with
+    the tiles the table picks for this call, and (forced_batch = 64) with every conv forced to the configuration
+    `bench.py --dtype fp8 --batch 64` (BASELINE.json configs[4]) launches, asserted per op"""
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.hip_backend import HipContext
+    from test_gpu_headline import force_batch32_tiles, _ran_tiles
     W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
     HH = WW = 640
     ctx = HipContext(W, device=0, dtype='fp8', max_batch=2, max_h=HH, max_w=WW)
@@ -133,7 +137,18 @@ def test_fp8_headline_topology_layers():
         # 8 + 12 + 4 + 4 backbone, 6 x 4 head; the four bottlenecks of the 80-channel block (layer 2) stay in 16 bits:
         # they run as fused launches (conv_v5c.cpp), faster than their e4m3 pair and exact
         assert ctx.lib.mdhip_fp8_num_tensors(ctx.h) == 52
+        forced = None
+        if forced_batch is not None:
+            ctx.forward(2, HH, WW)                 # (op_infos of a forward: geometry of every op)
+            forced = force_batch32_tiles(ctx, 2, HH, WW, batch=forced_batch)
+            assert len(forced) == 152, len(forced)
         ctx.forward(2, HH, WW)
+        if forced is not None:
+            ran = _ran_tiles(ctx, forced)
+            assert ran == forced
+            used = sorted(set(ran.values()))
+            print('fp8 x6: batch-{} tile configurations in use: {}'.format(forced_batch, used))
+            assert sum(1 for u in ran.values() if u.startswith('f8:')) == 52, used      # every bottleneck 3x3 outside layer 2
         x, _ = PU.oracle_input(imgs, WW, 64)
         keep = {}
         pred8, _ = PU.oracle_forward(W, x, 'fp8', keep=keep, fp8_scales=PU.fp8_scale_map(ctx))

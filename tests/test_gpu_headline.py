@@ -47,14 +47,15 @@ def _table_entries(ctx):
     return json.load(open(path))['entries']
 
 
-def force_batch32_tiles(ctx, n, h, w):
+def force_batch32_tiles(ctx, n, h, w, batch=32):
     """
-    Forces every conv op to the configuration the shipped table holds for it at batch 32 / 1280x1280 (matched on
+    Forces every conv op to the configuration the shipped table holds for it at batch `batch` / 1280x1280 (matched on
     the layer geometry N, K, taps, stride, residual; the entry whose per-image M is nearest), i.e. the kernels
     bench.py's step launches.  Returns {op index: configuration name}.
     """
     by_name = {ctx.conv_cfg_name(c): c for c in range(ctx.num_conv_cfgs())}
-    entries = [e for e in _table_entries(ctx) if int(e.get('batch', 32)) == 32]
+    entries = [e for e in _table_entries(ctx) if int(e.get('batch', 32)) == batch]
+    assert entries, 'the {} tile table has no entries measured at batch {}'.format(ctx.dtype, batch)
     forced = {}
     for o in ctx.op_infos():
         if o['kind'] != 0:
@@ -67,7 +68,7 @@ def force_batch32_tiles(ctx, n, h, w):
             cfg = by_name.get(e.get('name'), e['cfg'])
             if not ctx.op_supports_cfg(o['op'], cfg):
                 continue
-            r = max(e['m'] / 32 / m_img, m_img / (e['m'] / 32))
+            r = max(e['m'] / batch / m_img, m_img / (e['m'] / batch))
             if best is None or r < best[0]:
                 best = (r, cfg)
         if best is not None:
