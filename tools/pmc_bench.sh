@@ -50,7 +50,8 @@ for name in sorted(acc, key=lambda n: -sum(acc[n].get('SQ_BUSY_CYCLES', [0]))):
         # MFMA-pipe utilisation = matrix instructions x cycles each / (SIMDs x kernel cycles), kernel cycles from the
         # measured shader clock of the dispatch (GRBM_GUI_ACTIVE / duration); and against the 2.4 GHz the vendor peak
         # assumes (= achieved / peak FLOP/s for 16-bit launches)
-        clk = c.get('GRBM_GUI_ACTIVE', 0.0) / d_ns if c.get('GRBM_GUI_ACTIVE') else 0.0
+        # (GRBM_GUI_ACTIVE comes back summed over the 8 XCDs, each with its own GRBM)
+        clk = c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / d_ns if c.get('GRBM_GUI_ACTIVE') else 0.0
         per = 2.0 if 'f8' in name else 1.0
         busy = c['SQ_INSTS_MFMA'] * MFMA_CYCLES * per
         summary[name] = {'dispatch_us': d_ns / 1e3, 'shader_clock_ghz': clk or None,
