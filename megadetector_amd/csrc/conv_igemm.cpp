@@ -172,9 +172,9 @@ conv_igemm_kernel(const ConvArgs p) {
         }
         // descriptor based at the tile's first pixel minus the conv padding: every in-range tap
         // of every row of the tile has a small non-negative byte offset
-        const int b0 = m0 / p.HoWo;
+        const int b0 = conv_udiv(m0, p.HoWo, p.rcp_howo);
         const int rem0 = m0 - b0 * p.HoWo;
-        const int oy0 = rem0 / p.Wo;
+        const int oy0 = conv_udiv(rem0, p.Wo, p.rcp_wo);
         const int ox0 = rem0 - oy0 * p.Wo;
         const long long base_px = (long long)(b0 * p.H + oy0 * p.stride - p.pad) * p.W + (ox0 * p.stride - p.pad);
         a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + base_px * p.ld_in), 0, kNumRecords, 0x00020000);
@@ -185,21 +185,21 @@ conv_igemm_kernel(const ConvArgs p) {
             uint32_t mask = 0;
             unsigned off = 0;
             if (m < p.M) {
-                const int b = m / p.HoWo;
+                const int b = conv_udiv(m, p.HoWo, p.rcp_howo);
                 const int rem = m - b * p.HoWo;
-                const int oy = rem / p.Wo;
+                const int oy = conv_udiv(rem, p.Wo, p.rcp_wo);
                 const int ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad;
                 const int ix0 = ox * p.stride - p.pad;
                 const long long px = (long long)(b * p.H + iy0) * p.W + ix0;
                 off = (unsigned)((px - base_px) * p.ld_in * 2);
+                uint32_t cols = 0, rows = 0;         // kernels are 1x1 or 3x3 (planner enforces it): bit r * kw + s
 #pragma unroll
-                for (int r = 0; r < 3; ++r)          // kernels are 1x1 or 3x3 (planner enforces it)
-#pragma unroll
-                    for (int s = 0; s < 3; ++s)
-                        if (r < kh && s < p.kw && (unsigned)(iy0 + r) < (unsigned)p.H &&
-                            (unsigned)(ix0 + s) < (unsigned)p.W)
-                            mask |= 1u << (r * p.kw + s);
+                for (int t = 0; t < 3; ++t) {
+                    cols |= (t < p.kw && (unsigned)(ix0 + t) < (unsigned)p.W) ? 1u << t : 0u;
+                    rows |= (t < kh && (unsigned)(iy0 + t) < (unsigned)p.H) ? 1u << t : 0u;
+                }
+                mask = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << p.kw : 0u) | ((rows & 4u) ? cols << (2 * p.kw) : 0u);
             }
             a_off[i] = off;
             a_mask[i] = mask;
@@ -566,6 +566,7 @@ hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     if (a.in_f8) return hipErrorInvalidValue;
     const ConvCfg& c = g_cfgs[cfg];
     ConvArgs p = a;
+    conv_set_rcp(p);
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;
     p.tiles_m = (a.M + c.bm - 1) / c.bm;
     // persistent streams: about as many workgroups as fit on the chip at once (32 CUs per XCD);

@@ -155,9 +155,9 @@ conv_v2_kernel(const ConvArgs p) {
             return;
         }
         const int m0 = tile_m * BM;
-        const int b0 = m0 / p.HoWo;
+        const int b0 = conv_udiv(m0, p.HoWo, p.rcp_howo);
         const int rem0 = m0 - b0 * p.HoWo;
-        const int oy0 = rem0 / p.Wo;
+        const int oy0 = conv_udiv(rem0, p.Wo, p.rcp_wo);
         const int ox0 = rem0 - oy0 * p.Wo;
         const long long base_px = (long long)(b0 * p.H + oy0 * p.stride - p.pad) * p.W + (ox0 * p.stride - p.pad);
         a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + base_px * p.ld_in), 0, kNumRecords, 0x00020000);
@@ -168,9 +168,9 @@ conv_v2_kernel(const ConvArgs p) {
             uint32_t mask = 0;
             unsigned off = 0;
             if (m < p.M) {
-                const int b = m / p.HoWo;
+                const int b = conv_udiv(m, p.HoWo, p.rcp_howo);
                 const int rem = m - b * p.HoWo;
-                const int oy = rem / p.Wo;
+                const int oy = conv_udiv(rem, p.Wo, p.rcp_wo);
                 const int ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad;
                 const int ix0 = ox * p.stride - p.pad;
@@ -178,13 +178,15 @@ conv_v2_kernel(const ConvArgs p) {
                 off = (unsigned)((px - base_px) * p.ld_in * 2);
                 if constexpr (UP)
                     u_off[i] = (unsigned)((((long long)b * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.ld_up * 2 + jj * 16);
+                // tap (r, s) is inside the image iff row r and column s are: three row bits x three column bits
+                // (kernels are 1x1 or 3x3, bit r * kw + s)
+                uint32_t cols = 0, rows = 0;
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int s = 0; s < 3; ++s)
-                        if (r < kh && s < p.kw && (unsigned)(iy0 + r) < (unsigned)p.H &&
-                            (unsigned)(ix0 + s) < (unsigned)p.W)
-                            mask |= 1u << (r * p.kw + s);
+                for (int t = 0; t < 3; ++t) {
+                    cols |= (t < p.kw && (unsigned)(ix0 + t) < (unsigned)p.W) ? 1u << t : 0u;
+                    rows |= (t < kh && (unsigned)(iy0 + t) < (unsigned)p.H) ? 1u << t : 0u;
+                }
+                mask = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << p.kw : 0u) | ((rows & 4u) ? cols << (2 * p.kw) : 0u);
             }
             a_off[i] = off;
             a_mask[i] = mask;
@@ -577,6 +579,7 @@ hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     if (cfg < 0 || cfg >= conv2_num_cfgs() + kNumProf || !conv2_supports(a)) return hipErrorInvalidValue;
     const ConvCfg& c = g_cfgs2[cfg];
     ConvArgs p = a;
+    conv_set_rcp(p);
     p.tiles_n = (a.n_rows + c.bn - 1) / c.bn;
     p.tiles_m = (a.M + c.bm - 1) / c.bm;
     p.tiles_per_xcd = (p.tiles_m + 7) / 8;

@@ -174,7 +174,22 @@ struct ConvArgs {
     // concat buffer; nullptr = everything from `in`
     const uint16_t* in_up;
     int ld_up, up_slabs;
+    // floor(2^32 / HoWo), floor(2^32 / Wo) (0xffffffff for a divisor of 1): the tile set-up of the implicit-GEMM kernels
+    // splits an output pixel index into (image, row, column) with conv_udiv() instead of two run-time integer
+    // divisions per row; filled by conv_launch / conv2_launch (conv_set_rcp), callers leave them alone
+    unsigned rcp_howo, rcp_wo;
 };
+inline unsigned conv_rcp32(int d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned)d); }
+inline void conv_set_rcp(ConvArgs& p) { p.rcp_howo = conv_rcp32(p.HoWo); p.rcp_wo = conv_rcp32(p.Wo); }
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// m / d for 0 <= m < 2^31, d >= 1, rcp = floor(2^32 / d): the estimate mulhi(m, rcp) is the quotient or one below it
+// (m * (2^32 / d - rcp) / 2^32 < 1), one compare fixes it -- 5 instructions instead of the ~30 of a run-time division
+__device__ __forceinline__ int conv_udiv(int m, int d, unsigned rcp) {
+    unsigned q = __umulhi((unsigned)m, rcp);
+    const unsigned r = (unsigned)m - q * (unsigned)d;
+    return (int)(r >= (unsigned)d ? q + 1u : q);
+}
+#endif
 
 struct ConvCfg {
     int bm, bn, threads;

@@ -38,6 +38,8 @@ static const Shape kShapes[] = {
     {"l2_3x3", 32, 320, 320, 80, 80, 3, 1, true},       // M 3276800 N 80 K 720
     {"l29_3x3", 32, 40, 40, 480, 480, 3, 1, false},     // M 51200 N 480 K 4320
     {"l32_3x3", 32, 20, 20, 640, 640, 3, 1, false},     // M 12800 N 640 K 5760
+    {"gemm_l26", 32, 80, 80, 2880, 320, 1, 1, false},   // the L26 3x3's GEMM shape as a plain GEMM (1x1 over 2880 channels): M 204800 N 320 K 2880
+    {"gemm_l23", 32, 160, 160, 1472, 160, 1, 1, false}, // M 819200 N 160 K 1472 (= 23 slabs; the L23 3x3 has 1440)
     {"l26_1x1", 32, 80, 80, 320, 320, 1, 1, false},     // M 204800 N 320 K 320
     {"l23_1x1", 32, 160, 160, 160, 160, 1, 1, false},
     {"l2_1x1", 32, 320, 320, 80, 80, 1, 1, false},
