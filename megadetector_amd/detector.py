@@ -134,6 +134,29 @@ class HIPDetector:
         if weights.max_stride != self.letterbox_stride and verbose:
             print('*** Warning: model stride is {}, letterbox stride is {} ***'.format(
                 weights.max_stride, self.letterbox_stride))
+        # fp8 mode: where do the static activation scales come from?  Decided before anything touches the GPU, so that
+        # a missing calibration is an immediate, clear error (also in the parent of a multi-GPU run)
+        self._fp8_pending = False
+        self._fp8_scales_file = opts.get('fp8_scales_file') or None
+        fp8_scales = None
+        if str(opts.get('dtype') or DEFAULT_DTYPE).lower() == 'fp8':
+            fp8_scales = opts.get('fp8_scales')
+            if isinstance(fp8_scales, str):                   # "a;b;c" from a key=value command line
+                fp8_scales = [v for v in fp8_scales.replace(';', ' ').split() if v]
+            if not fp8_scales and self._fp8_scales_file and os.path.isfile(self._fp8_scales_file):
+                with open(self._fp8_scales_file, 'r') as f:
+                    fp8_scales = json.load(f)['fp8_scales']
+            if not fp8_scales:
+                if parse_bool_string(opts.get('fp8_calibrate_on_first_batch', False)):
+                    # explicit opt-in: the scales then come from whatever batch arrives first, i.e. the output depends
+                    # on file order / batch size / shard; with fp8_scales_file they are saved for the next run
+                    self._fp8_pending = True
+                else:
+                    raise ValueError(
+                        "dtype 'fp8' needs its activation scales: pass detector_options['fp8_scales'] (a list saved "
+                        "from HipContext.fp8_scales) or ['fp8_scales_file'] (json written by an earlier calibration), or "
+                        "opt into calibrating on the first batch with ['fp8_calibrate_on_first_batch']=True -- results "
+                        "then depend on that batch")
         from .hip_backend import HipContext
         self.max_batch = int(opts.get('batch_size', 1)) if int(opts.get('batch_size', 1)) > 1 else int(opts.get('max_batch', 8))
         max_size = int(opts.get('max_image_size', self.default_image_size))
@@ -143,27 +166,8 @@ class HIPDetector:
         self._ctx = HipContext(weights, device=_device_ordinal(device), dtype=opts.get('dtype') or DEFAULT_DTYPE,
                                max_batch=self.max_batch, max_h=max_size, max_w=max_size)
         self.model = self._ctx
-        self._fp8_pending = False
-        self._fp8_scales_file = opts.get('fp8_scales_file') or None
-        if self._ctx.dtype == 'fp8':
-            scales = opts.get('fp8_scales')
-            if isinstance(scales, str):                       # "a;b;c" from a key=value command line
-                scales = [v for v in scales.replace(';', ' ').split() if v]
-            if not scales and self._fp8_scales_file and os.path.isfile(self._fp8_scales_file):
-                with open(self._fp8_scales_file, 'r') as f:
-                    scales = json.load(f)['fp8_scales']
-            if scales:
-                self._ctx.set_fp8_scales([float(v) for v in scales])
-            elif parse_bool_string(opts.get('fp8_calibrate_on_first_batch', False)):
-                # explicit opt-in: the static scales then come from whatever batch arrives first, i.e. the output
-                # depends on file order / batch size / shard; with fp8_scales_file they are saved for the next run
-                self._fp8_pending = True
-            else:
-                raise ValueError(
-                    "dtype 'fp8' needs its activation scales: pass detector_options['fp8_scales'] (a list saved from "
-                    "HipContext.fp8_scales) or ['fp8_scales_file'] (json written by an earlier calibration), or opt "
-                    "into calibrating on the first batch with ['fp8_calibrate_on_first_batch']=True -- results then "
-                    "depend on that batch")
+        if fp8_scales:
+            self._ctx.set_fp8_scales([float(v) for v in fp8_scales])
 
     # -----------------------------------------------------------------------------------
     def preprocess_image(self, img_original, image_id='unknown', image_size=None, verbose=False):

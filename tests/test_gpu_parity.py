@@ -727,6 +727,13 @@ def test_test_time_augmentation_matches_oracle(n6):
     assert 'failure' not in r1 and r1['detections'] and r1 != r0
     want1 = PU.oracle_detections(torch.from_numpy(det._ctx.read_predictions(1)), infos[:1], (hh, ww), 1e-5)[0]
     assert r1['detections'] == want1['detections']
+    # ... and through the pipelined interface of the batch driver (start_batch / finish_batch take `augment` since
+    # round 3): the same detections as the synchronous call, plain and augmented
+    both = det.generate_detections_one_batch(list(imgs), ['a.jpg', 'b.jpg'], detection_threshold=1e-5, augment=True)
+    t = det.start_batch(list(imgs), ['a.jpg', 'b.jpg'], detection_threshold=1e-5, augment=True)
+    assert det.finish_batch(t) == both and both[0]['detections'] == r1['detections']
+    t = det.start_batch(list(imgs), ['a.jpg', 'b.jpg'], detection_threshold=1e-5)
+    assert det.finish_batch(t)[0]['detections'] == r0['detections']
 
 
 @pytest.mark.parametrize('shape', [(300, 400), (512, 384), (97, 211), (640, 640), (1000, 750), (256, 256), (150, 260)])
