@@ -131,7 +131,10 @@ def main():
     # one rank per GPU: CPUs of the GPU's NUMA node, disjoint from the other ranks' (the host thread formats 2.8 ms of
     # detections per step and keeps the queue fed; SURVEY.md 8(e) "scaling limiter")
     from megadetector_amd import placement
-    pinned_cpus = placement.pin_worker(local_rank, 1 if one_gpu else world, verbose=(world > 1))
+    pinned_cpus = placement.pin_worker(local_rank, 1 if one_gpu else world, verbose=False)
+    if world > 1:                                              # stdout carries the one JSON line and nothing else
+        print('rank {}: {} CPUs{}'.format(rank, len(pinned_cpus), ' ({}..{})'.format(pinned_cpus[0], pinned_cpus[-1])
+                                          if pinned_cpus else ''), file=sys.stderr)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -237,20 +237,44 @@ conv_f8_kernel(const ConvArgs p) {
     asm volatile("" : "+v"(unit_scale));             // a VGPR holding the E8M0 unit scale of both operands
 
     // ---- epilogue (conv_v5.cpp's, plus the per-channel scale) -----------------------------------------------
-    const int q4 = lane >> 4;
     auto epilogue_t = [&](int tile_m, auto has_res_t) __attribute__((always_inline)) {
         constexpr bool HAS_RES = decltype(has_res_t)::value;
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // MFMA (16 passes) write -> VALU read of the accumulators
-        const int m0 = tile_m * BM + wm * TM + (lane & 15);
+        // (an opaque copy of the lane id: lane-only offsets must not be hoisted ahead of the main loop, conv_v5.cpp)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int q4 = lane_e >> 4;
         const int nbase = n0 + wn * TN + q4 * 4;
         // bias and scale are re-read from LDS for every pixel row (volatile: 40 live registers less than keeping them
         // across the rows, which made the kernel spill)
         auto ld4 = [&](int off) -> f32x4 { return *(const volatile __attribute__((address_space(3))) f32x4*)(smem + off); };
+        // Outputs and the residual go through buffer instructions (conv_v5.cpp): one 32-bit offset register per lane and
+        // tensor instead of 64-bit address pairs, which were spilled and reloaded -- with an s_waitcnt vmcnt(0) each --
+        // in front of every store; rows past the tensor's end are dropped / read as zeros by the range check.
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        const int npair0 = n0 + wn * TN + q4 * 8;
+        const int nlast = nbase + (FN - 1) * 16;
+        // (descriptors start at the tile's first pixel: offsets stay small whatever the tensor's size)
+        const long long rows_left = (long long)p.M - (long long)tile_m * BM;
+        const int ml = wm * TM + (lane_e & 15);
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((uint16_t*)p.out + (size_t)tile_m * BM * p.ld_out), 0, (int)min(rows_left * p.ld_out * 2, 0x7fffffffLL), 0x00020000);
+        const unsigned o_pair = ((unsigned)ml * (unsigned)p.ld_out + (unsigned)npair0) * 2u;
+        const unsigned o_last = ((unsigned)ml * (unsigned)p.ld_out + (unsigned)nlast) * 2u;
+        const unsigned o_step = 16u * (unsigned)p.ld_out * 2u;
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.res + (HAS_RES ? (size_t)tile_m * BM * p.ld_res : 0)), 0,
+            HAS_RES ? (int)min(rows_left * p.ld_res * 2, 0x7fffffffLL) : 0, 0x00020000);
+        const unsigned r_col = ((unsigned)ml * (unsigned)p.ld_res + (unsigned)nbase) * 2u;
+        const unsigned r_step = 16u * (unsigned)p.ld_res * 2u;
         uint2 rrow[2][FN];
         auto fetch_res_row = [&](int i, uint2 (&r)[FN]) {
-            const int m = min(m0 + i * 16, p.M - 1);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) r[j] = *(const uint2*)(p.res + (size_t)m * p.ld_res + min(nbase + j * 16, p.N - 4));
+            for (int j = 0; j < FN; ++j) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, (int)(r_col + (unsigned)i * r_step + (unsigned)(j * 32)), 0, 0);
+                r[j] = make_uint2(t[0], t[1]);
+            }
         };
         if constexpr (HAS_RES) fetch_res_row(0, rrow[0]);
 #pragma unroll
@@ -258,7 +282,6 @@ conv_f8_kernel(const ConvArgs p) {
             if constexpr (HAS_RES) {
                 if (i + 1 < FM) fetch_res_row(i + 1, rrow[(i + 1) & 1]);
             }
-            const int m = m0 + i * 16;
             float v[FN][4];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
@@ -283,7 +306,6 @@ conv_f8_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(v[j][0]), "v"(v[j][1]), "v"(v[j][2]), "v"(v[j][3]));
             } else {
-                uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
                     unsigned a0 = st_pack2(v[j][0], v[j][1]), a1 = st_pack2(v[j][2], v[j][3]);
@@ -292,16 +314,14 @@ conv_f8_kernel(const ConvArgs p) {
                     auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
                     auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
-                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
-                    if (m < p.M && n < p.N) *(uint4*)(orow + n) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                    const unsigned off = o_pair + (unsigned)i * o_step + (unsigned)(j * 32);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{t0[0], t1[0], t0[1], t1[1]}, o_rsrc,
+                                                           (int)(npair0 + j * 16 < p.N ? off : kOOB), 0, 0);
                 }
                 if (FN & 1) {
                     const int j = FN - 1;
-                    const int n = nbase + j * 16;
-                    uint2 o;
-                    o.x = st_pack2(v[j][0], v[j][1]);
-                    o.y = st_pack2(v[j][2], v[j][3]);
-                    if (m < p.M && n < p.N) *(uint2*)(orow + n) = o;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{st_pack2(v[j][0], v[j][1]), st_pack2(v[j][2], v[j][3])}, o_rsrc,
+                                                          (int)(nlast < p.N ? o_last + (unsigned)i * o_step : kOOB), 0, 0);
                 }
             }
         }

@@ -48,6 +48,15 @@ typedef __attribute__((address_space(3))) char lds_char;
 __device__ __forceinline__ float silu_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
+// Two values at a time: the same operations and roundings as silu_f32 (x * -log2(e), v_exp_f32, 1 + e, v_rcp_f32, x * r),
+// with the four full-rate ones as packed fp32 instructions.  The two transcendentals (quarter rate) are what is left:
+// the epilogue of an 8-wave tile, where no other workgroup's MFMAs run under it, is bound by this arithmetic.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 silu_f32x2(f32x2 x, float neg_log2e) {
+    const f32x2 u = x * f32x2{neg_log2e, neg_log2e};
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + f32x2{1.0f, 1.0f};
+    return x * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+}
 
 constexpr int v5_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
 // the row of zeros (256 bytes) and, behind it, the staged bias of the workgroup's BN channels: whole KiB
@@ -135,8 +144,13 @@ conv_v5_kernel(const ConvArgs p) {
     const unsigned b_stride = (unsigned)(NW * 8 * p.k_pad4) * 2u;      // (LEAN) bytes between a wave's pieces
     int l_step = 0;                                // the weight loader's step inside a tile (same for every tile)
     auto b_voff = [&](int i) __attribute__((always_inline)) -> unsigned {
-        if constexpr (LEAN) return b_off[0] + (unsigned)i * b_stride;
-        else return b_off[i];
+        if constexpr (LEAN) {
+            // (the multiple of the stride is made opaque: the compiler would otherwise keep one precomputed offset
+            // register per piece alive through the loop -- the registers this form exists to save)
+            unsigned d = (unsigned)i * b_stride;
+            asm volatile("" : "+s"(d));
+            return b_off[0] + d;
+        } else return b_off[i];
     };
     auto dma_b_piece = [&](int stage, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
@@ -158,13 +172,18 @@ conv_v5_kernel(const ConvArgs p) {
     }
     const unsigned q_stride = (unsigned)(NW * 8 * p.ld_in) * 2u;
     auto q_voff = [&](int i) __attribute__((always_inline)) -> unsigned {
-        if constexpr (LEAN) return q_off[0] + (unsigned)i * q_stride;
-        else return q_off[i];
+        if constexpr (LEAN) {
+            unsigned d = (unsigned)i * q_stride;
+            asm volatile("" : "+s"(d));
+            return q_off[0] + d;
+        } else return q_off[i];
     };
     int lg_tile = first_tile, lg_cg = 0, lg_r = 0;
     bool lg_live = true;
     int lg_first = 0;                              // raster index of the run's first pixel (may be negative)
     unsigned lg_soff = 0;
+    unsigned lg_lo = 0;                            // (LEAN) byte offset of raster pixel 0 from the run's first pixel
+    const unsigned lg_span = (unsigned)p.M * (unsigned)p.ld_in * 2u;
     auto run_tile = [&](int t) __attribute__((always_inline)) {
         const long long origin = (long long)t * BM - p.W - 1;          // first pixel of the r = 0 run
         a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + origin * p.ld_in), 0, kNumRecords, 0x00020000);
@@ -172,13 +191,23 @@ conv_v5_kernel(const ConvArgs p) {
     auto run_setup = [&]() __attribute__((always_inline)) {
         lg_first = lg_tile * BM + (lg_r - 1) * p.W - 1;
         lg_soff = (unsigned)(lg_r * p.W * p.ld_in * 2 + lg_cg * 128);
+        if constexpr (LEAN) lg_lo = (unsigned)(-lg_first) * (unsigned)p.ld_in * 2u;
     };
     auto dma_run_piece = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
         if (i * NW + wave >= A_PIECES) return;                                                  // wave-uniform
-        const int q = (i * NW + wave) * 8 + lr;
-        const bool ok = lg_live && (unsigned)(lg_first + q) < (unsigned)p.M && lg_cg * 8 + jj < p.C8;
-        MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_voff(i) : kOOB, lg_soff);
+        if constexpr (LEAN) {
+            // pixel inside the batch, tested on the byte offset the piece is addressed with (a chunk offset is smaller
+            // than a pixel's stride, so  0 <= first + q < M  <=>  0 <= offset - lo < M * stride): no second per-lane
+            // register for the pixel index
+            const unsigned v = q_voff(i);
+            const bool ok = lg_live && (v - lg_lo) < lg_span && lg_cg * 8 + jj < p.C8;
+            MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? v : kOOB, lg_soff);
+        } else {
+            const int q = (i * NW + wave) * 8 + lr;
+            const bool ok = lg_live && (unsigned)(lg_first + q) < (unsigned)p.M && lg_cg * 8 + jj < p.C8;
+            MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_voff(i) : kOOB, lg_soff);
+        }
     };
     auto run_next = [&]() __attribute__((always_inline)) {
         if (++lg_r == 3) {
@@ -196,10 +225,23 @@ conv_v5_kernel(const ConvArgs p) {
     // run buffer: fragment row = wave row + i*16 + (lane & 15) + s; the 16-byte chunk of k-chunk c of
     // buffer row q sits at position c ^ (q & 7)
     const int c0 = lane >> 4;
-    unsigned a_sh[3];                              // byte offset inside a run buffer of fragment 0 at shift s
+    // byte offset inside a run buffer of fragment 0 at shift s: three registers, or (LEAN, which has none to spare)
+    // worked out again in every step from an opaque copy of the lane id, six VALU instructions under the MFMAs
+    auto a_shift = [&](int l, int s) __attribute__((always_inline)) -> unsigned {
+        return (unsigned)((wm * TM + (l & 15) + s) * 128 + (((l >> 4) ^ (((l & 7) + s) & 7)) << 4));
+    };
+    unsigned a_sh[LEAN ? 1 : 3];
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-        a_sh[s] = (unsigned)((wm * TM + (lane & 15) + s) * 128 + ((c0 ^ (((lane & 7) + s) & 7)) << 4));
+        for (int s = 0; s < 3; ++s) a_sh[s] = a_shift(lane, s);
+    }
+    auto a_shift_now = [&](int s) __attribute__((always_inline)) -> unsigned {
+        if constexpr (LEAN) {
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            return a_shift(l, s);
+        } else return a_sh[s];
+    };
     const unsigned z_addr = (unsigned)(ZERO_OFF + c0 * 16);
     const int b_frag_base = B_OFF + (wn * TN + (lane & 15)) * 128 + ((c0 ^ (lane & 7)) << 4);
     uint32_t vmask[FM];                            // tap-validity bits of this lane's FM pixels (tile being read)
@@ -222,8 +264,8 @@ conv_v5_kernel(const ConvArgs p) {
             vmask[i] = mask;
         }
     };
-    auto set_a_eff_one = [&](int buf, int r, int s, int i) __attribute__((always_inline)) {
-        const unsigned a = a_sh[s] + (unsigned)(buf * A_BUF + i * 2048);
+    auto set_a_eff_one = [&](int buf, int r, int s, int i, unsigned a_s) __attribute__((always_inline)) {
+        const unsigned a = a_s + (unsigned)(buf * A_BUF + i * 2048);
         a_eff[i] = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
     };
     auto read_x = [&](int i, int kk) -> frag8_t {
@@ -242,17 +284,58 @@ conv_v5_kernel(const ConvArgs p) {
 
     // ---- epilogue (as conv_v2: scalar bias, pixel-row order, 16-byte stores) --------------------------
     const int q4 = lane >> 4;
-    auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t) __attribute__((always_inline)) {
+    auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t, auto act_t) __attribute__((always_inline)) {
+        // (x * r and the residual add stay two roundings -- as in every other kernel family, where a select on the
+        // activation flag sits between them: the results of the network do not depend on which tile a layer got)
+#pragma clang fp contract(off)
         constexpr bool HAS_RES = decltype(has_res_t)::value;
         constexpr bool OUT_F32 = decltype(out_f32_t)::value;
-        const int m0 = tile_m * BM + wm * TM + (lane & 15);
-        const int nbase = n0 + wn * TN + q4 * 4;
-        float bv[FN][4];
+        constexpr bool ACT_FIXED = decltype(act_t)::value;
+        // (set here, opaquely: as a compile-time constant it is put into a register pair ahead of the main loop, which
+        // has none to spare)
+        float neg_log2e = -0x1.715476p+0f;
+        asm volatile("" : "+v"(neg_log2e));
+        // After the exchanges below, lane (pixel p = lane & 15, q = lane >> 4) holds 16 bytes = channels q*8 .. q*8+7 of a
+        // 32-channel column pair and stores them from there.  (Moving the chunk of (p, q) to lane 4*p + q first -- four
+        // adjacent lanes write 64 contiguous bytes, a quarter wave touches 4 cache lines instead of 16 -- was measured:
+        // the ds_bpermutes cost 2-5 % more than the address path saves, profiles/r3_convbench_epilogue.txt.)
+        // (from an opaque copy of the lane id: everything below that depends only on the lane -- with tile-relative
+        // descriptors that is every offset of every row -- would otherwise be computed once ahead of the main loop,
+        // spilled there, and reloaded in front of each store behind an s_waitcnt vmcnt(0))
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int lp = lane_e & 15;
+        const int lq = lane_e >> 4;
+        const int m0 = tile_m * BM + wm * TM + lp;
+        const int nbase = n0 + wn * TN + q4 * 4;                       // accumulator layout (fp32 outputs)
+        const int nlast = n0 + wn * TN + (FN - 1) * 16 + lq * 4;       // this lane's 4 channels of an odd last column
+        // 16-bit outputs and the residual go through buffer instructions: ONE 32-bit offset register per lane and tensor
+        // (column pairs sit at immediate offsets), rows past the tensor's end are dropped / read as zeros by the range
+        // check.  With 64-bit global addresses the compiler kept an address pair per column alive across the tile's main
+        // loop, spilled them, and reloaded one before every store -- each reload an s_waitcnt vmcnt(0), i.e. a full
+        // write round trip per store and no residual row ever in flight behind the one being finished.
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        const int npair0 = n0 + wn * TN + lq * 8;                      // first of this lane's 8 channels of column pair 0
+        // (descriptors start at the tile's first pixel: offsets stay small whatever the tensor's size)
+        const long long rows_left = (long long)p.M - (long long)tile_m * BM;
+        const int ml = wm * TM + lp;                                    // this lane's pixel inside the tile (+ 16 per row i)
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((uint16_t*)p.out + (size_t)tile_m * BM * p.ld_out), 0, (int)min(rows_left * p.ld_out * 2, 0x7fffffffLL), 0x00020000);
+        const unsigned o_pair = ((unsigned)ml * (unsigned)p.ld_out + (unsigned)npair0) * 2u;
+        const unsigned o_last = ((unsigned)ml * (unsigned)p.ld_out + (unsigned)nlast) * 2u;
+        const unsigned o_step = 16u * (unsigned)p.ld_out * 2u;
+        // (8-wave tiles: every channel of the tile exists, conv5_supports)
+        auto n_ok = [&](int n) __attribute__((always_inline)) -> bool { return LEAN || n < p.N; };
+        // (8-wave tiles: the bias is read from LDS again for every pixel row; 20 registers the epilogue does not have)
+        constexpr bool BIAS_PER_ROW = LEAN;
+        f32x4 bv[FN];
+        auto read_bias = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const f32x4 g = *(const __attribute__((address_space(3))) f32x4*)(smem + ZERO_OFF + 256 + (wn * TN + j * 16 + q4 * 4) * 4);
-            bv[j][0] = g[0]; bv[j][1] = g[1]; bv[j][2] = g[2]; bv[j][3] = g[3];
-        }
+            for (int j = 0; j < FN; ++j)
+                bv[j] = *(const __attribute__((address_space(3))) f32x4*)(smem + ZERO_OFF + 256 + (wn * TN + j * 16 + q4 * 4) * 4);
+        };
+        if constexpr (!BIAS_PER_ROW) read_bias();
         // The residual is read the way the output is written: 16 bytes per lane = 8 consecutive channels of a pair of
         // fragment columns (64 contiguous bytes per pixel and instruction, 3 loads per pixel row instead of 5), and
         // brought back to the accumulator layout by the inverse of the store exchange (v_permlane16_swap, then
@@ -264,15 +347,23 @@ conv_v5_kernel(const ConvArgs p) {
         constexpr int RA = LEAN ? 2 : 1, RS = RA + 1;
         uint4 rpair[RS][NPAIR > 0 ? NPAIR : 1];
         uint2 rlast[RS];
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.res + (HAS_RES ? (size_t)tile_m * BM * p.ld_res : 0)), 0,
+            HAS_RES ? (int)min(rows_left * p.ld_res * 2, 0x7fffffffLL) : 0, 0x00020000);
+        const unsigned r_pair = ((unsigned)ml * (unsigned)p.ld_res + (unsigned)npair0) * 2u;
+        const unsigned r_last = ((unsigned)ml * (unsigned)p.ld_res + (unsigned)nlast) * 2u;
+        const unsigned r_step = 16u * (unsigned)p.ld_res * 2u;
         auto fetch_res_row = [&](int i, uint4 (&rp)[NPAIR > 0 ? NPAIR : 1], uint2& rl) {
-            // branch-free (clamped) addresses: a load under a divergent branch would make the compiler
-            // fall back from counted vmcnt waits to vmcnt(0), which also waits for stores
-            const int m = min(m0 + i * 16, p.M - 1);
-            const uint16_t* rrow_p = p.res + (size_t)m * p.ld_res;
+            // (no branches, no clamps: what lies outside the tensor reads as zero and is never stored)
 #pragma unroll
-            for (int jp = 0; jp < NPAIR; ++jp)
-                rp[jp] = *(const uint4*)(rrow_p + min(n0 + wn * TN + jp * 32 + q4 * 8, p.N - 8));
-            if (FN & 1) rl = *(const uint2*)(rrow_p + min(nbase + (FN - 1) * 16, p.N - 4));
+            for (int jp = 0; jp < NPAIR; ++jp) {
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, (int)(r_pair + (unsigned)i * r_step + (unsigned)(jp * 64)), 0, 0);
+                rp[jp] = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            if (FN & 1) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, (int)(r_last + (unsigned)i * r_step), 0, 0);
+                rl = make_uint2(t[0], t[1]);
+            }
         };
         if constexpr (HAS_RES) {
 #pragma unroll
@@ -284,14 +375,18 @@ conv_v5_kernel(const ConvArgs p) {
                 if (i + RA < FM) fetch_res_row(i + RA, rpair[(i + RA) % RS], rlast[(i + RA) % RS]);
             }
             const int m = m0 + i * 16;
+            if constexpr (BIAS_PER_ROW) read_bias();
             float v[FN][4];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][r] + bv[j][r];
-                    if ((PROF & 4) == 0 && p.act) t = silu_f32(t);
-                    v[j][r] = t;
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2 t = f32x2{acc[i][j][r], acc[i][j][r + 1]} + f32x2{bv[j][r], bv[j][r + 1]};
+                    if constexpr ((PROF & 4) == 0) {
+                        if (ACT_FIXED || p.act) t = silu_f32x2(t, neg_log2e);
+                    }
+                    v[j][r] = t[0];
+                    v[j][r + 1] = t[1];
                 }
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -312,7 +407,9 @@ conv_v5_kernel(const ConvArgs p) {
                     add4(2 * jp, a0[0], a1[0]);
                     add4(2 * jp + 1, a0[1], a1[1]);
                 }
-                if (FN & 1) add4(FN - 1, rlast[i % RS].x, rlast[i % RS].y);
+                if (FN & 1) {
+                    add4(FN - 1, rlast[i % RS].x, rlast[i % RS].y);
+                }
             }
             if constexpr ((PROF & 2) != 0) {
 #pragma unroll
@@ -325,7 +422,6 @@ conv_v5_kernel(const ConvArgs p) {
                         *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 }
             } else {
-                uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
                     unsigned a0 = st_pack2(v[j][0], v[j][1]), a1 = st_pack2(v[j][2], v[j][3]);
@@ -334,24 +430,31 @@ conv_v5_kernel(const ConvArgs p) {
                     auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
                     auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
-                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
-                    if (m < p.M && n < p.N) *(uint4*)(orow + n) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                    const uint4 o = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                    const unsigned off = o_pair + (unsigned)i * o_step + (unsigned)(j * 32);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{o.x, o.y, o.z, o.w}, o_rsrc,
+                                                           (int)(n_ok(npair0 + j * 16) ? off : kOOB), 0, 0);
                 }
                 if (FN & 1) {
                     const int j = FN - 1;
-                    const int n = nbase + j * 16;
-                    uint2 o;
-                    o.x = st_pack2(v[j][0], v[j][1]);
-                    o.y = st_pack2(v[j][2], v[j][3]);
-                    if (m < p.M && n < p.N) *(uint2*)(orow + n) = o;
+                    const uint2 o = make_uint2(st_pack2(v[j][0], v[j][1]), st_pack2(v[j][2], v[j][3]));
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{o.x, o.y}, o_rsrc,
+                                                          (int)(n_ok(nlast) ? o_last + (unsigned)i * o_step : kOOB), 0, 0);
                 }
             }
         }
     };
+    // The 8-wave tiles are built for activated 16-bit outputs only (conv5_supports): two epilogues, no select per value.
+    // The others take the activation flag at run time (std::false_type = "ask p.act").
     auto epilogue = [&](int tile_m) __attribute__((always_inline)) {
-        if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{});
-        else if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{});
-        else epilogue_t(tile_m, std::false_type{}, std::false_type{});
+        if constexpr (LEAN) {
+            if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::true_type{});
+            else epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::true_type{});
+        } else {
+            if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{}, std::false_type{});
+            else if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::false_type{});
+            else epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::false_type{});
+        }
     };
 
     // ---- prologue: run (first tile, group 0, r 0) in buffer 0, weight slabs of steps 0 and 1 ----------
@@ -381,13 +484,14 @@ conv_v5_kernel(const ConvArgs p) {
     frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
     tile_masks(first_tile);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) set_a_eff_one(0, 0, 0, i);
+    for (int i = 0; i < FM; ++i) set_a_eff_one(0, 0, 0, i, a_shift_now(0));
 #pragma unroll
     for (int i = 0; i < FM; ++i) xa[i] = read_x(i, 0);
 #pragma unroll
     for (int j = 0; j < FN; ++j) wa[j] = read_w(0, 0, j);
 
     int c_r = 0, c_cg = 0, c_tile = first_tile, pa = 0, step = 0;
+    [[maybe_unused]] bool after_epilogue = false;
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if constexpr ((PROF & 1) != 0) {
@@ -413,6 +517,7 @@ conv_v5_kernel(const ConvArgs p) {
             const int nbuf = s == 2 ? pa ^ 1 : pa;
             const int nr = s == 2 ? n_r : c_r;
             if (s == 2 && tile_end) tile_masks(c_tile + tile_step);       // (masks of a tile past the stream's end are never used)
+            const unsigned a_next = a_shift_now(ns);
             // ---- first half: k 0..31 of this step, while its k 32..63 fragments are read and the
             //      fragment addresses of the next step are selected; MFMA chunk g = fragment column g ----
 #pragma unroll
@@ -421,10 +526,10 @@ conv_v5_kernel(const ConvArgs p) {
                 // spare fragment, read first): 6 weight fragments live instead of 10
                 if constexpr (LEAN) wb[(g + FN - 1) % FN] = read_w(cur, 1, (g + FN - 1) % FN);
                 else wb[g] = read_w(cur, 1, g);
-                if (g < FM) { xb[g] = read_x(g, 1); set_a_eff_one(nbuf, nr, ns, g); }
+                if (g < FM) { xb[g] = read_x(g, 1); set_a_eff_one(nbuf, nr, ns, g, a_next); }
                 if (g == FN - 1) {
 #pragma unroll
-                    for (int i = FN; i < FM; ++i) { xb[i] = read_x(i, 1); set_a_eff_one(nbuf, nr, ns, i); }
+                    for (int i = FN; i < FM; ++i) { xb[i] = read_x(i, 1); set_a_eff_one(nbuf, nr, ns, i, a_next); }
                 }
                 MDHIP_FENCE();
 #pragma unroll
@@ -436,9 +541,12 @@ conv_v5_kernel(const ConvArgs p) {
             stamp(0);
             // everything this wave requested has landed; its reads of weight stage `cur` are complete
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            stamp(1);
+            // (stamps: the wait and the barrier of the first step after an epilogue -- whose stores this wait also
+            // covers -- are booked under slot 4)
+            if (after_epilogue) stamp(4); else stamp(1);
             __builtin_amdgcn_s_barrier();
-            stamp(2);
+            if (after_epilogue) stamp(4); else stamp(2);
+            after_epilogue = false;
             MDHIP_FENCE();
 
             // ---- second half: the k 0..31 fragments of the next step, MFMAs on k 32..63, and the DMA
@@ -478,6 +586,7 @@ conv_v5_kernel(const ConvArgs p) {
         if (n_r == 0 && ++c_cg == G) {
             c_cg = 0;
             epilogue(c_tile);
+            after_epilogue = true;
             c_tile += tile_step;
         }
         stamp(5);
@@ -513,7 +622,9 @@ conv_v5_kernel(const ConvArgs p) {
     X(11, 320, 160, 4, 2, 1) \
     X(12, 320, 160, 4, 2, 16) \
     X(13, 320, 160, 4, 2, 6) \
-    X(14, 320, 160, 4, 2, 22)
+    X(14, 320, 160, 4, 2, 22) \
+    X(15, 320, 160, 4, 2, 2) \
+    X(16, 320, 160, 4, 2, 3)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
@@ -522,7 +633,7 @@ static const ConvCfg g_cfgs5[] = {
     MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
 #undef X
 };
-constexpr int kNumProf5 = 7;
+constexpr int kNumProf5 = 9;
 
 // ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp and the C = 80
 // strip kernel of conv_v5c.cpp (same K order, same results), then the developer variants
@@ -555,7 +666,8 @@ bool conv5_supports(int cfg, const ConvArgs& a) {
                     a.Wo == a.W && a.C8 >= 8 && (a.N % 8) == 0 &&
                     (long long)(2 * a.W + conv5_cfg(cfg).bm + 16) * a.ld_in * 2 + 4096 < 0x7fffffffLL;
     if (ok && cfg < kNumMain5 && g_cfgs5[cfg].threads >= 512 && g_cfgs5[cfg].bm * g_cfgs5[cfg].bn == 160 * 320 &&
-        (a.n_rows % g_cfgs5[cfg].bn) != 0)
+        ((a.n_rows % g_cfgs5[cfg].bn) != 0 || !a.act || a.out_f32 ||
+         ((long long)a.M + g_cfgs5[cfg].bm + 2 * a.W + 16) * a.ld_in * 2 >= 0xffffffffLL))
         return false;                                     // the 80x80-wave-tile configurations (LEAN)
     if (ok && cfg >= kNumMain5 && cfg < first5c()) return conv5s_supports(cfg - kNumMain5, a);
     if (ok && cfg >= first5c() && cfg < conv5_num_cfgs()) return conv5c_supports(cfg - first5c(), a);

@@ -95,6 +95,8 @@ def main():
             ctx.set_op_cfg(o['op'], -1)
             cache[sig] = ms
         b = int(np.argmin(ms))
+        if not np.isfinite(ms[b]):          # nothing could be timed (e.g. an op that runs inside a fused launch): the table keeps what it has
+            continue
         tf = [o['flops'] / (t * 1e-3) / 1e12 if np.isfinite(t) else 0.0 for t in ms]
         entries[sig] = dict(m=sig[0], n=sig[1], k=sig[2], ntaps=sig[3], stride=sig[4], has_res=sig[5], cfg=b,
                             batch=B, ms=round(ms[b], 5), tflops=round(tf[b], 1), name=ctx.conv_cfg_name(b))

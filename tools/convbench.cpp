@@ -35,6 +35,8 @@ static const Shape kShapes[] = {
     {"l26_3x3", 32, 80, 80, 320, 320, 3, 1, false},     // M 204800 N 320 K 2880  (x20, 20% of the net)
     {"l6_3x3r", 32, 80, 80, 320, 320, 3, 1, true},      // same with residual (backbone)
     {"l23_3x3", 32, 160, 160, 160, 160, 3, 1, false},   // M 819200 N 160 K 1440
+    {"l4_3x3r", 32, 160, 160, 160, 160, 3, 1, true},    // same with residual (backbone C3 of layer 4)
+    {"l8_3x3r", 32, 40, 40, 480, 480, 3, 1, true},      // M 51200 N 480 K 4320 with residual
     {"l2_3x3", 32, 320, 320, 80, 80, 3, 1, true},       // M 3276800 N 80 K 720
     {"l29_3x3", 32, 40, 40, 480, 480, 3, 1, false},     // M 51200 N 480 K 4320
     {"l32_3x3", 32, 20, 20, 640, 640, 3, 1, false},     // M 12800 N 640 K 5760
@@ -323,7 +325,7 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 6; ++k) sum[k] += (double)h[w * 8 + k];
             }
             static const char* nm5[6] = {"half1 (reads Y + mfma X)", "waitcnt vmcnt/lgkmcnt", "barrier", "half2 (dma + reads X + mfma Y)",
-                                         "advance", "epilogue (amortised)"};
+                                         "first step after an epilogue: wait + barrier", "epilogue (amortised)"};
             const char* const* nm = nm5;
             double tot = 0;
             for (int k = 0; k < 6; ++k) tot += sum[k];
