@@ -277,15 +277,13 @@ conv_igemm_kernel(const ConvArgs p) {
             for (int j = 0; j < FN; ++j) {
                 const int nl = nl0 + j * 16;
                 const float4 bv = *(const __attribute__((address_space(3))) float4*)(smem + BIAS_OFF + nl * 4);
-                v[j][0] = acc[i][j][0] + bv.x;
-                v[j][1] = acc[i][j][1] + bv.y;
-                v[j][2] = acc[i][j][2] + bv.z;
-                v[j][3] = acc[i][j][3] + bv.w;
+                const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+                mdhip_bias4(acc[i][j], b4, v[j]);
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.act) {
-                    v[j][0] = silu_f32(v[j][0]); v[j][1] = silu_f32(v[j][1]);
-                    v[j][2] = silu_f32(v[j][2]); v[j][3] = silu_f32(v[j][3]);
-                }
+            }
+            if (p.act) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mdhip_silu4(v[j]);
             }
             if (p.res) {
 #pragma unroll

@@ -268,11 +268,39 @@ conv_v2_kernel(const ConvArgs p) {
     // fragment column ahead of their use, so waiting for them never waits for a store.
     const int q4 = lane >> 4;
     auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t, auto out_f8_t) {
+        // (x * r and the residual add stay two roundings whatever the shape of the code between them)
+#pragma clang fp contract(off)
         constexpr bool HAS_RES = decltype(has_res_t)::value;
         constexpr bool OUT_F32 = decltype(out_f32_t)::value;
         constexpr bool OUT_F8 = decltype(out_f8_t)::value;
         const int m0 = tile_m * BM + wm * TM + (lane & 15);
         const int nbase = n0 + wn * TN + q4 * 4;
+        // 16-bit outputs and the residual go through buffer instructions (see conv_v5.cpp): one 32-bit offset per lane
+        // and tensor, tile-relative descriptors, rows past the end dropped / read as zeros by the range check -- no
+        // 64-bit address arithmetic and no branch around every store.  The offsets come from an opaque copy of the lane
+        // id so that they are computed here and not kept alive across the main loop.
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        float neg_log2e = kNegLog2e;                             // (opaque: not a register pair kept across the main loop)
+        asm volatile("" : "+v"(neg_log2e));
+        const int ml = wm * TM + (lane_e & 15);
+        const int qe = lane_e >> 4;
+        const int npair0 = n0 + wn * TN + qe * 8;                 // first of this lane's 8 channels of column pair 0
+        const int nlast = n0 + wn * TN + (FN - 1) * 16 + qe * 4;  // its 4 channels of an odd last column
+        const long long rows_left = (long long)p.M - (long long)tile_m * BM;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((uint16_t*)p.out + (size_t)tile_m * BM * p.ld_out), 0,
+            (OUT_F32 || OUT_F8) ? 0 : (int)min(rows_left * p.ld_out * 2, 0x7fffffffLL), 0x00020000);
+        const unsigned o_pair = ((unsigned)ml * (unsigned)p.ld_out + (unsigned)npair0) * 2u;
+        const unsigned o_last = ((unsigned)ml * (unsigned)p.ld_out + (unsigned)nlast) * 2u;
+        const unsigned o_step = 16u * (unsigned)p.ld_out * 2u;
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.res + (HAS_RES ? (size_t)tile_m * BM * p.ld_res : 0)), 0,
+            HAS_RES ? (int)min(rows_left * p.ld_res * 2, 0x7fffffffLL) : 0, 0x00020000);
+        const unsigned r_col = ((unsigned)ml * (unsigned)p.ld_res + (unsigned)(n0 + wn * TN + qe * 4)) * 2u;
+        const unsigned r_step = 16u * (unsigned)p.ld_res * 2u;
         // bias of all fragment columns first (scalar loads), then pixel-row by pixel-row so that the
         // stores that complete one cache line are issued back to back
         // bias of all fragment columns first (scalar loads), then pixel-row by pixel-row so that the
@@ -299,9 +327,11 @@ conv_v2_kernel(const ConvArgs p) {
         }
         uint2 rrow[2][FN];
         auto fetch_res_row = [&](int i, uint2 (&r)[FN]) {
-            const int m = min(m0 + i * 16, p.M - 1);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) r[j] = *(const uint2*)(p.res + (size_t)m * p.ld_res + min(nbase + j * 16, p.N - 4));
+            for (int j = 0; j < FN; ++j) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, (int)(r_col + (unsigned)i * r_step + (unsigned)(j * 32)), 0, 0);
+                r[j] = make_uint2(t[0], t[1]);
+            }
         };
         if constexpr (HAS_RES) fetch_res_row(0, rrow[0]);
 #pragma unroll
@@ -311,15 +341,31 @@ conv_v2_kernel(const ConvArgs p) {
             }
             const int m = m0 + i * 16;
             float v[FN][4];
+            // bias, then the activation of the whole pixel row under ONE uniform branch (no select per value), two values
+            // per instruction wherever the instruction set has a packed form
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][r] + bv[j][r];
-                    if ((PROF & 4) == 0 && p.act) t = silu_f32(t);
-                    v[j][r] = t;
+                for (int r = 0; r < 4; r += 2) {
+                    const mdhip_f32x2 t = mdhip_f32x2{acc[i][j][r], acc[i][j][r + 1]} + mdhip_f32x2{bv[j][r], bv[j][r + 1]};
+                    v[j][r] = t[0];
+                    v[j][r + 1] = t[1];
                 }
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if ((PROF & 4) == 0 && p.act) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const mdhip_f32x2 t = silu_f32x2(mdhip_f32x2{v[j][r], v[j][r + 1]}, neg_log2e);
+                        v[j][r] = t[0];
+                        v[j][r + 1] = t[1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
                 if constexpr (HAS_RES) {
                     const uint2 rv = rrow[i & 1][j];
                     v[j][0] += st_unpack((uint16_t)(rv.x & 0xffff));
@@ -341,26 +387,27 @@ conv_v2_kernel(const ConvArgs p) {
             } else if constexpr (OUT_F8) {
                 // e4m3 output (MDHIP_DTYPE_FP8: the hidden tensor of a bottleneck): 4 channels = 4 bytes per lane and
                 // fragment; the same exchange as the 16-bit path leaves 8 consecutive channels = 8 bytes per lane
-                uint8_t* orow8 = (uint8_t*)p.out + (size_t)m * p.ld_out;
+                const __amdgpu_buffer_rsrc_t o8_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)((uint8_t*)p.out + (size_t)tile_m * BM * p.ld_out), 0, (int)min(rows_left * p.ld_out, 0x7fffffffLL), 0x00020000);
+                const unsigned row8 = (unsigned)(ml + i * 16) * (unsigned)p.ld_out;
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
                     const unsigned a0 = pack_e4m3x4(v[j][0], v[j][1], v[j][2], v[j][3], p.out_qscale);
                     const unsigned b0 = pack_e4m3x4(v[j + 1][0], v[j + 1][1], v[j + 1][2], v[j + 1][3], p.out_qscale);
                     const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                     const auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
-                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
-                    if (m < p.M && n < p.N) *(uint2*)(orow8 + n) = make_uint2(t0[0], t0[1]);
+                    const int n = npair0 + j * 16;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{t0[0], t0[1]}, o8_rsrc, (int)(n < p.N ? row8 + (unsigned)n : kOOB), 0, 0);
                 }
                 if (FN & 1) {
                     const int j = FN - 1;
-                    const int n = nbase + j * 16;
-                    if (m < p.M && n < p.N) *(unsigned*)(orow8 + n) = pack_e4m3x4(v[j][0], v[j][1], v[j][2], v[j][3], p.out_qscale);
+                    __builtin_amdgcn_raw_buffer_store_b32(pack_e4m3x4(v[j][0], v[j][1], v[j][2], v[j][3], p.out_qscale), o8_rsrc,
+                                                          (int)(nlast < p.N ? row8 + (unsigned)nlast : kOOB), 0, 0);
                 }
             } else {
                 // bf16: pairs of fragment columns are exchanged across the four 16-lane rows
                 // (v_permlane32_swap, v_permlane16_swap) so that a lane holds 8 consecutive channels
                 // = 16 bytes, and one store covers 64 contiguous bytes per pixel instead of 32
-                uint16_t* orow = (uint16_t*)p.out + (size_t)m * p.ld_out;
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
                     unsigned a0 = st_pack2(v[j][0], v[j][1]), a1 = st_pack2(v[j][2], v[j][3]);
@@ -370,16 +417,14 @@ conv_v2_kernel(const ConvArgs p) {
                     auto t0 = __builtin_amdgcn_permlane16_swap(s0[0], s0[1], false, false);
                     auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
                     // row q of the wave now holds channels q*8 .. q*8+7 of the 32 channels of this pair
-                    const int n = n0 + wn * TN + j * 16 + q4 * 8;
-                    if (m < p.M && n < p.N) *(uint4*)(orow + n) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                    const unsigned off = o_pair + (unsigned)i * o_step + (unsigned)(j * 32);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{t0[0], t1[0], t0[1], t1[1]}, o_rsrc,
+                                                           (int)(npair0 + j * 16 < p.N ? off : kOOB), 0, 0);
                 }
                 if (FN & 1) {
                     const int j = FN - 1;
-                    const int n = nbase + j * 16;
-                    uint2 o;
-                    o.x = st_pack2(v[j][0], v[j][1]);
-                    o.y = st_pack2(v[j][2], v[j][3]);
-                    if (m < p.M && n < p.N) *(uint2*)(orow + n) = o;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{st_pack2(v[j][0], v[j][1]), st_pack2(v[j][2], v[j][3])}, o_rsrc,
+                                                          (int)(nlast < p.N ? o_last + (unsigned)i * o_step : kOOB), 0, 0);
                 }
             }
         }

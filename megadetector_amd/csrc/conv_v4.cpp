@@ -281,13 +281,15 @@ conv_v4_kernel(const ConvArgs p) {
             float v[FN][4];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][r] + bv[j][r];
-                    if ((PROF & 4) == 0 && p.act) t = silu_f32(t);
-                    v[j][r] = t;
-                }
+                mdhip_bias4(acc[i][j], bv[j], v[j]);
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if ((PROF & 4) == 0 && p.act) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mdhip_silu4(v[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
                 if constexpr (HAS_RES) {
                     const uint2 rv = rrow[i & 1][j];
                     v[j][0] += st_unpack((uint16_t)(rv.x & 0xffff));

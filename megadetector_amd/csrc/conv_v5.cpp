@@ -48,15 +48,7 @@ typedef __attribute__((address_space(3))) char lds_char;
 __device__ __forceinline__ float silu_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
-// Two values at a time: the same operations and roundings as silu_f32 (x * -log2(e), v_exp_f32, 1 + e, v_rcp_f32, x * r),
-// with the four full-rate ones as packed fp32 instructions.  The two transcendentals (quarter rate) are what is left:
-// the epilogue of an 8-wave tile, where no other workgroup's MFMAs run under it, is bound by this arithmetic.
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ f32x2 silu_f32x2(f32x2 x, float neg_log2e) {
-    const f32x2 u = x * f32x2{neg_log2e, neg_log2e};
-    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + f32x2{1.0f, 1.0f};
-    return x * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
-}
+typedef mdhip_f32x2 f32x2;
 
 constexpr int v5_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
 // the row of zeros (256 bytes) and, behind it, the staged bias of the workgroup's BN channels: whole KiB

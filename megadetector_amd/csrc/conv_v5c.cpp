@@ -216,12 +216,8 @@ conv_c80_kernel(const ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][r] + bias4[r];
-                    if (p.act) t = silu_f32(t);
-                    v[r] = t;
-                }
+                mdhip_bias4(acc[i], bias4, v);
+                if (p.act) mdhip_silu4(v);
                 acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (p.res) {
                     v[0] += st_unpack((uint16_t)(rres[i][0] & 0xffff));
@@ -364,8 +360,8 @@ conv_c80f_kernel(const ConvArgs p) {
                 const int px = (wm * TFW + f) * 16 + m15;
                 const bool ok = row_ok && px < BM + 2 && (unsigned)(x0 - 1 + px) < (unsigned)p.W;
                 float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_f32(c[r] + bpre4[r]);
+                mdhip_bias4(c, bpre4, v);
+                mdhip_silu4(v);
                 uint2 d;
                 d.x = ok ? st_pack2(v[0], v[1]) : 0u;
                 d.y = ok ? st_pack2(v[2], v[3]) : 0u;
@@ -442,12 +438,8 @@ conv_c80f_kernel(const ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][r] + bias4[r];
-                    if (p.act) t = silu_f32(t);
-                    v[r] = t;
-                }
+                mdhip_bias4(acc[i], bias4, v);
+                if (p.act) mdhip_silu4(v);
                 acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (p.res) {
                     v[0] += st_unpack((uint16_t)(rres[i][0] & 0xffff));

@@ -250,13 +250,12 @@ conv_v5s_kernel(const ConvArgs p) {
             float v[FN][4];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][r] + bv[j][r];
-                    if (p.act) t = silu_f32(t);
-                    v[j][r] = t;
-                }
+                mdhip_bias4(acc[i][j], bv[j], v[j]);
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.act) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mdhip_silu4(v[j]);
             }
             if constexpr (HAS_RES) {
                 auto add4 = [&](int j, unsigned lo, unsigned hi) {

@@ -158,8 +158,8 @@ conv_stem_kernel(const ConvArgs p) {
 #pragma unroll
             for (int j = 0; j < kFN; ++j) {
                 const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(smem + kBiasOff + (j * 16 + q4 * 4) * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[j][r] = silu_f32(acc[i][j][r] + bv[r]);
+                mdhip_bias4(acc[i][j], bv, v[j]);
+                mdhip_silu4(v[j]);
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll

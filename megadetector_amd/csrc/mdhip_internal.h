@@ -189,6 +189,30 @@ __device__ __forceinline__ int conv_udiv(int m, int d, unsigned rcp) {
     const unsigned r = (unsigned)m - q * (unsigned)d;
     return (int)(r >= (unsigned)d ? q + 1u : q);
 }
+// SiLU of two values at a time: the same operations and roundings as the scalar  x * rcp(1 + exp(-x))  of every kernel
+// family (x * -log2(e), v_exp_f32, 1 + e, v_rcp_f32, x * r), with the four full-rate ones as packed fp32 instructions.
+// The two transcendentals are quarter rate: for 1x1 convs with K <= 640 the activation is more VALU time than the
+// layer's MFMAs are matrix time, so the epilogues are written around it.  (neg_log2e: -0x1.715476p+0f, passed in so that
+// register-tight kernels can keep it out of the main loop.)
+typedef __attribute__((ext_vector_type(2))) float mdhip_f32x2;
+constexpr float kNegLog2e = -0x1.715476p+0f;
+__device__ __forceinline__ mdhip_f32x2 silu_f32x2(mdhip_f32x2 x, float neg_log2e = kNegLog2e) {
+    const mdhip_f32x2 u = x * mdhip_f32x2{neg_log2e, neg_log2e};
+    const mdhip_f32x2 e = mdhip_f32x2{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + mdhip_f32x2{1.0f, 1.0f};
+    return x * mdhip_f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+}
+// v[0..3] = a[0..3] + b[0..3] (packed), the first half of every epilogue; the activation follows under one uniform branch
+// per pixel row (mdhip_silu4), not as a select per value
+template <typename A, typename B>
+__device__ __forceinline__ void mdhip_bias4(const A& a, const B& b, float (&v)[4]) {
+    const mdhip_f32x2 t0 = mdhip_f32x2{a[0], a[1]} + mdhip_f32x2{b[0], b[1]};
+    const mdhip_f32x2 t1 = mdhip_f32x2{a[2], a[3]} + mdhip_f32x2{b[2], b[3]};
+    v[0] = t0[0]; v[1] = t0[1]; v[2] = t1[0]; v[3] = t1[1];
+}
+__device__ __forceinline__ void mdhip_silu4(float (&v)[4], float neg_log2e = kNegLog2e) {
+    const mdhip_f32x2 t0 = silu_f32x2(mdhip_f32x2{v[0], v[1]}, neg_log2e), t1 = silu_f32x2(mdhip_f32x2{v[2], v[3]}, neg_log2e);
+    v[0] = t0[0]; v[1] = t0[1]; v[2] = t1[0]; v[3] = t1[1];
+}
 #endif
 
 struct ConvCfg {
