@@ -135,6 +135,11 @@ conv_v5_kernel(const ConvArgs p) {
     }
     const unsigned b_stride = (unsigned)(NW * 8 * p.k_pad4) * 2u;      // (LEAN) bytes between a wave's pieces
     int l_step = 0;                                // the weight loader's step inside a tile (same for every tile)
+    // LEAN: a piece is issued with as few instructions as the hardware needs -- every instruction between two MFMA chunks
+    // is matrix-pipe idle time, because the two waves of a SIMD run the same code between the same barriers.  Weight
+    // pieces: the lane offset never changes, (step, piece) go into the scalar offset.  Run pieces: addressed from the
+    // tensor's first byte through a descriptor that covers exactly the tensor, so that the range check does what a
+    // compare + select per piece did (an offset "before" the tensor wraps to a huge one); see dma_run_piece.
     auto b_voff = [&](int i) __attribute__((always_inline)) -> unsigned {
         if constexpr (LEAN) {
             // (the multiple of the stride is made opaque: the compiler would otherwise keep one precomputed offset
@@ -147,7 +152,13 @@ conv_v5_kernel(const ConvArgs p) {
     auto dma_b_piece = [&](int stage, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
         if ((B_PIECES % NW) != 0 && i == B_PER - 1 && wave >= B_PIECES % NW) return;           // wave-uniform
-        MDHIP_DMA16(b_rsrc, smem + B_OFF + stage * B_BYTES + (i * NW + wave) * 1024, b_voff(i), l_step * 128);
+        if constexpr (LEAN) {
+            unsigned so = (unsigned)l_step * 128u + (unsigned)i * b_stride;
+            asm volatile("" : "+s"(so));
+            MDHIP_DMA16(b_rsrc, smem + B_OFF + stage * B_BYTES + (i * NW + wave) * 1024, b_off[0], so);
+        } else {
+            MDHIP_DMA16(b_rsrc, smem + B_OFF + stage * B_BYTES + (i * NW + wave) * 1024, b_voff(i), l_step * 128);
+        }
     };
     auto dma_b_done = [&]() __attribute__((always_inline)) { l_step = (l_step + 1 == steps_per_tile) ? 0 : l_step + 1; };
 
@@ -156,6 +167,8 @@ conv_v5_kernel(const ConvArgs p) {
     // the whole batch), channels cg*64 .. cg*64+63.  Pixels outside the batch read zeros; pixels that
     // are inside the batch but outside the image for some tap are dealt with at the fragment read.
     __amdgpu_buffer_rsrc_t a_rsrc = b_rsrc;
+    if constexpr (LEAN)                            // (conv5_supports: the tensor is smaller than 4 GiB)
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((unsigned)p.M * (unsigned)p.ld_in * 2u), 0x00020000);
     unsigned q_off[LEAN ? 1 : A_PER];              // byte offset of this lane's pixel + chunk from the run's first pixel
 #pragma unroll
     for (int i = 0; i < (LEAN ? 1 : A_PER); ++i) {
@@ -174,27 +187,28 @@ conv_v5_kernel(const ConvArgs p) {
     bool lg_live = true;
     int lg_first = 0;                              // raster index of the run's first pixel (may be negative)
     unsigned lg_soff = 0;
-    unsigned lg_lo = 0;                            // (LEAN) byte offset of raster pixel 0 from the run's first pixel
-    const unsigned lg_span = (unsigned)p.M * (unsigned)p.ld_in * 2u;
+    unsigned lg_abs = 0;                           // (LEAN) byte offset of (run's first pixel, channel group) in the tensor, mod 2^32
     auto run_tile = [&](int t) __attribute__((always_inline)) {
+        if constexpr (LEAN) return;
         const long long origin = (long long)t * BM - p.W - 1;          // first pixel of the r = 0 run
         a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + origin * p.ld_in), 0, kNumRecords, 0x00020000);
     };
     auto run_setup = [&]() __attribute__((always_inline)) {
         lg_first = lg_tile * BM + (lg_r - 1) * p.W - 1;
         lg_soff = (unsigned)(lg_r * p.W * p.ld_in * 2 + lg_cg * 128);
-        if constexpr (LEAN) lg_lo = (unsigned)(-lg_first) * (unsigned)p.ld_in * 2u;
+        if constexpr (LEAN) lg_abs = (unsigned)lg_first * (unsigned)p.ld_in * 2u + (unsigned)(lg_cg * 128);
     };
     auto dma_run_piece = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
         if (i * NW + wave >= A_PIECES) return;                                                  // wave-uniform
         if constexpr (LEAN) {
-            // pixel inside the batch, tested on the byte offset the piece is addressed with (a chunk offset is smaller
-            // than a pixel's stride, so  0 <= first + q < M  <=>  0 <= offset - lo < M * stride): no second per-lane
-            // register for the pixel index
-            const unsigned v = q_voff(i);
-            const bool ok = lg_live && (v - lg_lo) < lg_span && lg_cg * 8 + jj < p.C8;
-            MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? v : kOOB, lg_soff);
+            // Pixels outside the batch (before the first / behind the last image) fall outside the descriptor and read
+            // zeros.  No channel test: the tensors these tiles take have a multiple of 32 channels (conv5_supports), so
+            // the only chunks past the last channel are k 32..63 of a half-full last group, which no MFMA reads
+            // (tail_short).  After the stream's last tile the loader re-reads runs of that tile into buffers nobody reads.
+            unsigned so = lg_abs + (unsigned)i * q_stride;
+            asm volatile("" : "+s"(so));
+            MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, q_off[0] + so, 0);
         } else {
             const int q = (i * NW + wave) * 8 + lr;
             const bool ok = lg_live && (unsigned)(lg_first + q) < (unsigned)p.M && lg_cg * 8 + jj < p.C8;
@@ -259,6 +273,9 @@ conv_v5_kernel(const ConvArgs p) {
     auto set_a_eff_one = [&](int buf, int r, int s, int i, unsigned a_s) __attribute__((always_inline)) {
         const unsigned a = a_s + (unsigned)(buf * A_BUF + i * 2048);
         a_eff[i] = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
+        // (pinned here, in the first half of a step: left alone the compiler sinks the select into the second half, next
+        // to the read that uses it -- the half that also issues the DMA pieces and has no instruction slot to spare)
+        if constexpr (LEAN) asm volatile("" : "+v"(a_eff[i]));
     };
     auto read_x = [&](int i, int kk) -> frag8_t {
         return *(const __attribute__((address_space(3))) frag8_t*)(smem + (a_eff[i] ^ (unsigned)(kk * 64)));
@@ -455,9 +472,13 @@ conv_v5_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         if (i * NW + wave < A_PIECES) {
-            const int q = (i * NW + wave) * 8 + lr;
-            const bool ok = (unsigned)(lg_first + q) < (unsigned)p.M && jj < p.C8;
-            MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, ok ? q_voff(i) : kOOB, lg_soff);
+            if constexpr (LEAN) {
+                MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, q_off[0] + lg_abs + (unsigned)i * q_stride, 0);
+            } else {
+                const int q = (i * NW + wave) * 8 + lr;
+                const bool ok = (unsigned)(lg_first + q) < (unsigned)p.M && jj < p.C8;
+                MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, ok ? q_voff(i) : kOOB, lg_soff);
+            }
         }
     }
     run_next();
@@ -658,7 +679,7 @@ bool conv5_supports(int cfg, const ConvArgs& a) {
                     a.Wo == a.W && a.C8 >= 8 && (a.N % 8) == 0 &&
                     (long long)(2 * a.W + conv5_cfg(cfg).bm + 16) * a.ld_in * 2 + 4096 < 0x7fffffffLL;
     if (ok && cfg < kNumMain5 && g_cfgs5[cfg].threads >= 512 && g_cfgs5[cfg].bm * g_cfgs5[cfg].bn == 160 * 320 &&
-        ((a.n_rows % g_cfgs5[cfg].bn) != 0 || !a.act || a.out_f32 ||
+        ((a.n_rows % g_cfgs5[cfg].bn) != 0 || !a.act || a.out_f32 || (a.C8 % 4) != 0 ||
          ((long long)a.M + g_cfgs5[cfg].bm + 2 * a.W + 16) * a.ld_in * 2 >= 0xffffffffLL))
         return false;                                     // the 80x80-wave-tile configurations (LEAN)
     if (ok && cfg >= kNumMain5 && cfg < first5c()) return conv5s_supports(cfg - kNumMain5, a);
