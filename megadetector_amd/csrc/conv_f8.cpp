@@ -145,7 +145,11 @@ conv_f8_kernel(const ConvArgs p) {
     // ---- run loader (conv_v5.cpp): buffer row q of run (tile, cg, r) = input pixel tile*BM + (r-1)*W - 1 + q,
     //      channels cg*128 .. cg*128+127; one byte per channel, ld_in bytes per pixel ------------------------
     const uint8_t* const in8 = (const uint8_t*)p.in;
-    __amdgpu_buffer_rsrc_t a_rsrc = b_rsrc;
+    // (as conv_v5.cpp: one descriptor over the whole tensor, a piece is addressed from the tensor's first byte and the range
+    // check zeroes the pixels outside the batch; the channel test stays -- an e4m3 MFMA reads all 128 channels of a group, and
+    // what lies behind the last channel must be zeros, not the next pixel)
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)in8, 0, (int)((unsigned)p.M * (unsigned)p.ld_in), 0x00020000);
     unsigned q_off[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
@@ -153,31 +157,24 @@ conv_f8_kernel(const ConvArgs p) {
         q_off[i] = (unsigned)(q * p.ld_in + jj * 16);
     }
     int lg_tile = first_tile, lg_cg = 0, lg_r = 0;
-    bool lg_live = true;
     int lg_first = 0;
-    unsigned lg_soff = 0;
-    auto run_tile = [&](int t) __attribute__((always_inline)) {
-        const long long origin = (long long)t * BM - p.W - 1;
-        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(in8 + origin * p.ld_in), 0, kNumRecords, 0x00020000);
-    };
+    unsigned lg_abs = 0;                           // byte offset of (run's first pixel, channel group) in the tensor, mod 2^32
     auto run_setup = [&]() __attribute__((always_inline)) {
         lg_first = lg_tile * BM + (lg_r - 1) * p.W - 1;
-        lg_soff = (unsigned)(lg_r * p.W * p.ld_in + lg_cg * 128);
+        lg_abs = (unsigned)lg_first * (unsigned)p.ld_in + (unsigned)(lg_cg * 128);
     };
     auto dma_run_piece = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
         if (i * NW + wave >= A_PIECES) return;                                                  // wave-uniform
-        const int q = (i * NW + wave) * 8 + lr;
-        const bool ok = lg_live && (unsigned)(lg_first + q) < (unsigned)p.M && lg_cg * 8 + jj < p.C8;
-        MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_off[i] : kOOB, lg_soff);
+        const bool ok = jj < p.C8 - lg_cg * 8;
+        MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_off[i] + lg_abs : kOOB, 0);
     };
     auto run_next = [&]() __attribute__((always_inline)) {
         if (++lg_r == 3) {
             lg_r = 0;
             if (++lg_cg == G) {
                 lg_cg = 0;
-                if (lg_tile == last_tile) lg_live = false;
-                else { lg_tile += tile_step; run_tile(lg_tile); }
+                if (lg_tile != last_tile) lg_tile += tile_step;
             }
         }
         run_setup();
@@ -215,6 +212,7 @@ conv_f8_kernel(const ConvArgs p) {
     auto set_a_eff_one = [&](int buf, int r, int s, int i) __attribute__((always_inline)) {
         const unsigned a = a_sh[s] + (unsigned)(buf * A_BUF + i * 2048);
         a_eff[i] = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
+        asm volatile("" : "+v"(a_eff[i]));         // (pinned where it is written, conv_v5.cpp)
     };
     auto ld16 = [&](unsigned addr) -> i32x4 {
         return *(const __attribute__((address_space(3))) i32x4*)(smem + addr);
@@ -332,15 +330,11 @@ conv_f8_kernel(const ConvArgs p) {
     };
 
     // ---- prologue: run (first tile, group 0, r 0) in buffer 0, weight slabs of steps 0 and 1 ----------
-    run_tile(first_tile);
     run_setup();
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        if (i * NW + wave < A_PIECES) {
-            const int q = (i * NW + wave) * 8 + lr;
-            const bool ok = (unsigned)(lg_first + q) < (unsigned)p.M && jj < p.C8;
-            MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, ok ? q_off[i] : kOOB, lg_soff);
-        }
+        if (i * NW + wave < A_PIECES)
+            MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, jj < p.C8 ? q_off[i] + lg_abs : kOOB, 0);
     }
     run_next();
 #pragma unroll
@@ -515,7 +509,7 @@ bool conv8_supports(int cfg, const ConvArgs& a) {
     if (cfg < 0 || cfg >= conv8_num_cfgs() + kNumProf8) return false;
     return a.in_f8 && !a.out_f8 && !a.out_f32 && a.wgt8 != nullptr && a.scale != nullptr && a.ntaps == 9 && a.kw == 3 &&
            a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && a.C8 >= 1 && (a.N % 8) == 0 &&
-           (long long)(2 * a.W + g_cfgs8[cfg].bm + 16) * a.ld_in + 4096 < 0x7fffffffLL;
+           ((long long)a.M + 2 * a.W + g_cfgs8[cfg < conv8_num_cfgs() ? cfg : 0].bm + 16) * a.ld_in < 0x7fffffffLL;   // one descriptor over the tensor
 }
 
 hipError_t conv8_launch(int cfg, const ConvArgs& a, hipStream_t s) {

@@ -166,9 +166,9 @@ conv_v5_kernel(const ConvArgs p) {
     // Buffer row q of run (tile, cg, r) holds input pixel  tile*BM + (r-1)*W - 1 + q  (raster index over
     // the whole batch), channels cg*64 .. cg*64+63.  Pixels outside the batch read zeros; pixels that
     // are inside the batch but outside the image for some tap are dealt with at the fragment read.
-    __amdgpu_buffer_rsrc_t a_rsrc = b_rsrc;
-    if constexpr (LEAN)                            // (conv5_supports: the tensor is smaller than 4 GiB)
-        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((unsigned)p.M * (unsigned)p.ld_in * 2u), 0x00020000);
+    // (conv5_supports: the tensor is smaller than 4 GiB)
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((unsigned)p.M * (unsigned)p.ld_in * 2u), 0x00020000);
     unsigned q_off[LEAN ? 1 : A_PER];              // byte offset of this lane's pixel + chunk from the run's first pixel
 #pragma unroll
     for (int i = 0; i < (LEAN ? 1 : A_PER); ++i) {
@@ -176,43 +176,29 @@ conv_v5_kernel(const ConvArgs p) {
         q_off[i] = (unsigned)(q * p.ld_in * 2 + jj * 16);
     }
     const unsigned q_stride = (unsigned)(NW * 8 * p.ld_in) * 2u;
-    auto q_voff = [&](int i) __attribute__((always_inline)) -> unsigned {
-        if constexpr (LEAN) {
-            unsigned d = (unsigned)i * q_stride;
-            asm volatile("" : "+s"(d));
-            return q_off[0] + d;
-        } else return q_off[i];
-    };
     int lg_tile = first_tile, lg_cg = 0, lg_r = 0;
-    bool lg_live = true;
     int lg_first = 0;                              // raster index of the run's first pixel (may be negative)
-    unsigned lg_soff = 0;
-    unsigned lg_abs = 0;                           // (LEAN) byte offset of (run's first pixel, channel group) in the tensor, mod 2^32
-    auto run_tile = [&](int t) __attribute__((always_inline)) {
-        if constexpr (LEAN) return;
-        const long long origin = (long long)t * BM - p.W - 1;          // first pixel of the r = 0 run
-        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + origin * p.ld_in), 0, kNumRecords, 0x00020000);
-    };
+    unsigned lg_abs = 0;                           // byte offset of (run's first pixel, channel group) in the tensor, mod 2^32
     auto run_setup = [&]() __attribute__((always_inline)) {
         lg_first = lg_tile * BM + (lg_r - 1) * p.W - 1;
-        lg_soff = (unsigned)(lg_r * p.W * p.ld_in * 2 + lg_cg * 128);
-        if constexpr (LEAN) lg_abs = (unsigned)lg_first * (unsigned)p.ld_in * 2u + (unsigned)(lg_cg * 128);
+        lg_abs = (unsigned)lg_first * (unsigned)p.ld_in * 2u + (unsigned)(lg_cg * 128);
     };
+    // A run piece is addressed from the tensor's first byte: pixels outside the batch (before the first / behind the last
+    // image) fall outside the descriptor and read zeros -- the range check does what a compare + select per piece would.
+    // The 8-wave tiles do not test channels either: the tensors they take have a multiple of 32 channels (conv5_supports),
+    // so the only chunks past the last channel are k 32..63 of a half-full last group, which no MFMA reads (tail_short).
+    // After the stream's last tile the loader re-reads runs of that tile into buffers nobody reads.
     auto dma_run_piece = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
         if (i * NW + wave >= A_PIECES) return;                                                  // wave-uniform
         if constexpr (LEAN) {
-            // Pixels outside the batch (before the first / behind the last image) fall outside the descriptor and read
-            // zeros.  No channel test: the tensors these tiles take have a multiple of 32 channels (conv5_supports), so
-            // the only chunks past the last channel are k 32..63 of a half-full last group, which no MFMA reads
-            // (tail_short).  After the stream's last tile the loader re-reads runs of that tile into buffers nobody reads.
             unsigned so = lg_abs + (unsigned)i * q_stride;
             asm volatile("" : "+s"(so));
             MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, q_off[0] + so, 0);
         } else {
-            const int q = (i * NW + wave) * 8 + lr;
-            const bool ok = lg_live && (unsigned)(lg_first + q) < (unsigned)p.M && lg_cg * 8 + jj < p.C8;
-            MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_voff(i) : kOOB, lg_soff);
+            // (the tiles with registers to spare keep the channel test: any channel count that is a multiple of 8)
+            const bool ok = jj < p.C8 - lg_cg * 8;
+            MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_off[i] + lg_abs : 0xffffff00u, 0);
         }
     };
     auto run_next = [&]() __attribute__((always_inline)) {
@@ -220,8 +206,7 @@ conv_v5_kernel(const ConvArgs p) {
             lg_r = 0;
             if (++lg_cg == G) {
                 lg_cg = 0;
-                if (lg_tile == last_tile) lg_live = false;
-                else { lg_tile += tile_step; run_tile(lg_tile); }
+                if (lg_tile != last_tile) lg_tile += tile_step;
             }
         }
         run_setup();
@@ -275,7 +260,7 @@ conv_v5_kernel(const ConvArgs p) {
         a_eff[i] = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
         // (pinned here, in the first half of a step: left alone the compiler sinks the select into the second half, next
         // to the read that uses it -- the half that also issues the DMA pieces and has no instruction slot to spare)
-        if constexpr (LEAN) asm volatile("" : "+v"(a_eff[i]));
+        asm volatile("" : "+v"(a_eff[i]));
     };
     auto read_x = [&](int i, int kk) -> frag8_t {
         return *(const __attribute__((address_space(3))) frag8_t*)(smem + (a_eff[i] ^ (unsigned)(kk * 64)));
@@ -467,18 +452,12 @@ conv_v5_kernel(const ConvArgs p) {
     };
 
     // ---- prologue: run (first tile, group 0, r 0) in buffer 0, weight slabs of steps 0 and 1 ----------
-    run_tile(first_tile);
     run_setup();
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         if (i * NW + wave < A_PIECES) {
-            if constexpr (LEAN) {
-                MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, q_off[0] + lg_abs + (unsigned)i * q_stride, 0);
-            } else {
-                const int q = (i * NW + wave) * 8 + lr;
-                const bool ok = (unsigned)(lg_first + q) < (unsigned)p.M && jj < p.C8;
-                MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024, ok ? q_voff(i) : kOOB, lg_soff);
-            }
+            MDHIP_DMA16(a_rsrc, smem + (i * NW + wave) * 1024,
+                        (LEAN || jj < p.C8) ? (LEAN ? q_off[0] + (unsigned)i * q_stride : q_off[i]) + lg_abs : 0xffffff00u, 0);
         }
     }
     run_next();
@@ -678,9 +657,11 @@ bool conv5_supports(int cfg, const ConvArgs& a) {
     const bool ok = a.wgt4 != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H &&
                     a.Wo == a.W && a.C8 >= 8 && (a.N % 8) == 0 &&
                     (long long)(2 * a.W + conv5_cfg(cfg).bm + 16) * a.ld_in * 2 + 4096 < 0x7fffffffLL;
+    // the run loader addresses the whole tensor through one descriptor (dma_run_piece)
+    if (ok && (cfg < kNumMain5 || cfg >= conv5_num_cfgs()) && ((long long)a.M + 320 + 2 * a.W + 16) * a.ld_in * 2 >= 0xffffff00LL)
+        return false;
     if (ok && cfg < kNumMain5 && g_cfgs5[cfg].threads >= 512 && g_cfgs5[cfg].bm * g_cfgs5[cfg].bn == 160 * 320 &&
-        ((a.n_rows % g_cfgs5[cfg].bn) != 0 || !a.act || a.out_f32 || (a.C8 % 4) != 0 ||
-         ((long long)a.M + g_cfgs5[cfg].bm + 2 * a.W + 16) * a.ld_in * 2 >= 0xffffffffLL))
+        ((a.n_rows % g_cfgs5[cfg].bn) != 0 || !a.act || a.out_f32 || (a.C8 % 4) != 0))
         return false;                                     // the 80x80-wave-tile configurations (LEAN)
     if (ok && cfg >= kNumMain5 && cfg < first5c()) return conv5s_supports(cfg - kNumMain5, a);
     if (ok && cfg >= first5c() && cfg < conv5_num_cfgs()) return conv5c_supports(cfg - first5c(), a);
