@@ -143,15 +143,21 @@ conv_v2_kernel(const ConvArgs p) {
     // (its own instantiation -- conv2_launch picks it -- so that the 3x3 / strided launches keep the code they had)
     auto init_tile = [&](int tile_m) __attribute__((always_inline)) {
         if constexpr (PW) {
+            // the descriptor ends with the tensor: rows past the last pixel read zeros through the range check, no mask
+            // test per piece; a lane's offset (row of the tile, 16-byte chunk) never changes, the slab goes into the
+            // scalar offset -- a piece is issued with no VALU instruction at all (every instruction between two MFMA
+            // chunks is matrix-pipe idle time: the waves of a SIMD run the same code between the same barriers)
             const int m0 = tile_m * BM;
-            a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long long)m0 * p.ld_in), 0, kNumRecords, 0x00020000);
+            const long long left = ((long long)p.M - m0) * p.ld_in * 2;
+            a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long long)m0 * p.ld_in), 0,
+                                                       (int)(left > 0x7fffffffLL ? 0x7fffffffLL : left), 0x00020000);
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const int row = (i * NW + wave) * 8 + lr;
-                a_off[i] = (unsigned)(row * p.ld_in * 2);
-                a_mask[i] = (m0 + row < p.M) ? 1u : 0u;
+                a_off[i] = (unsigned)(row * p.ld_in * 2 + jj * 16);
+                a_mask[i] = 1u;
             }
-            c8 = jj; ts = 0; tapbit = 1; tapoff = (unsigned)jj * 16u;
+            c8 = jj; ts = 0; tapbit = 1; tapoff = 0;
             return;
         }
         const int m0 = tile_m * BM;
@@ -229,13 +235,18 @@ conv_v2_kernel(const ConvArgs p) {
                 return;
             }
         }
-        const unsigned voff = (a_mask[i] & tapbit) ? a_off[i] + tapoff : kOOB;
-        MDHIP_DMA16(a_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, voff, 0);
+        if constexpr (PW) {
+            MDHIP_DMA16(a_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, a_off[i], l_kt * 128);
+        } else {
+            const unsigned voff = (a_mask[i] & tapbit) ? a_off[i] + tapoff : kOOB;
+            MDHIP_DMA16(a_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, voff, 0);
+        }
     };
     auto dma_b = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
         if (B_RAGGED && i == B_PER - 1 && wave >= B_INSTR % NW) return;     // wave-uniform
-        const unsigned voff = l_live ? b_off[i] : kOOB;
+        // (PW: after the stream's last slab the loader re-reads slabs of the last tile into stages nobody reads)
+        const unsigned voff = (PW || l_live) ? b_off[i] : kOOB;
         MDHIP_DMA16(b_rsrc, smem + buf * STAGE + A_BYTES + (i * NW + wave) * 1024, voff, l_kt * 128);
     };
 
