@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument('--host-fed', action='store_true',
                     help='inputs start in pinned host memory and cross PCIe inside the timed region (H2D on a copy '
                          'stream, overlapped with the previous step); reported as the PCIe-inclusive rate, NOT the headline value')
+    ap.add_argument('--graph', default='off', choices=['auto', 'on', 'off'],
+                    help="graph replay of the forward (mdhip_set_graph; 'auto' = batches <= 8).  Off like the detector's default: "
+                         "measured, no gain (profiles/r3_graph_replay.txt)")
     ap.add_argument('--lean', action='store_true',
                     help='only warm-up + timed steps (no per-stage / per-op extras): for rocprofv3 runs')
     ap.add_argument('--cpu-seconds', type=float, default=14.0)
@@ -156,6 +159,7 @@ def main():
     yaml = getattr(yolo_yaml, args.model)
     weights = weights_io.synthetic_weights(yaml, seed=0)
     ctx = HipContext(weights, device=local_rank, dtype=args.dtype, max_batch=B, max_h=S, max_w=S)
+    ctx.set_graph(args.graph)
 
     # measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json) are loaded by HipContext
     if args.no_table:

@@ -239,6 +239,14 @@ int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n);
  * 4x copy (the upsample launch is skipped).  Same arithmetic and summation order: bit-identical results.  on = 0 runs
  * the separate launches (A/B measurements, tests). */
 int mdhip_set_fuse(mdhip_ctx* ctx, int on);
+/* Graph replay of mdhip_forward (default off): the launches of one forward -- ~160 kernels, which at batch 1 .. 4 do a few
+ * microseconds of work each -- are captured once per (batch, height, width) on an internal stream and replayed with one
+ * hipGraphLaunch on the caller's stream.  mode 0 = off, 1 = every forward, 2 = forwards of at most max_n images (max_n <= 0
+ * keeps the current bound, 8).  The first forward of a shape always runs eagerly; calls that change what a forward
+ * launches (mdhip_set_tuned, mdhip_set_op_cfg, mdhip_set_fuse, fp8 scales) drop the captured graphs.  Same kernels, same
+ * arguments: bit-identical results.  mdhip_forward_tta and the timed / per-op entry points are not replayed.
+ * Replaces nothing in the reference (pytorch_detector.py:1313 runs eager PyTorch); this is launch plumbing. */
+int mdhip_set_graph(mdhip_ctx* ctx, int mode, int max_n);
 /* time one op in isolation: `iters` back-to-back launches bracketed by events */
 int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float* ms_avg,
                   void* hip_stream);

@@ -24,7 +24,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/mdhip.h"
@@ -151,6 +153,13 @@ struct mdhip_ctx {
     int32_t* nms_host_cnt[MDHIP_NMS_SLOTS] = {};
     hipEvent_t nms_ev[MDHIP_NMS_SLOTS] = {};
     int nms_slot_n[MDHIP_NMS_SLOTS] = {};
+    // mdhip_set_graph: the op sequence of a forward captured once per (batch, height, width, prediction buffer) and
+    // replayed with one hipGraphLaunch (small batches are bound by ~160 launches of a few microseconds of work each)
+    int graph_mode = 0;                                   // 0 = off, 1 = on, 2 = on for batches <= graph_max_n
+    int graph_max_n = 8;
+    hipStream_t capture_stream = nullptr;
+    struct GraphSlot { hipGraphExec_t exec = nullptr; int seen = 0; };
+    std::map<std::tuple<int, int, int, int>, GraphSlot> graphs;
 };
 
 namespace {
@@ -163,6 +172,13 @@ int fail(mdhip_ctx* ctx, int code, const char* fmt, ...) {
     va_end(ap);
     if (ctx) ctx->err = buf; else g_create_error = buf;
     return code;
+}
+
+// every call that changes what a forward launches drops the captured graphs
+void drop_graphs(mdhip_ctx* ctx) {
+    for (auto& kv : ctx->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    ctx->graphs.clear();
 }
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -624,6 +640,7 @@ int check_calibrated(mdhip_ctx* ctx) {
 
 // new range -> scale of an e4m3 tensor and the combined per-channel factors of the conv that reads it
 int apply_fp8_scale(mdhip_ctx* ctx, Op& producer, float act_scale) {
+    drop_graphs(ctx);                               // (the quantisation scale is a launch argument)
     producer.act_scale = act_scale;
     Op& consumer = ctx->ops[producer.f8_peer];
     consumer.act_scale = act_scale;
@@ -1160,6 +1177,8 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
 void mdhip_destroy(mdhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    drop_graphs(ctx);
+    if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     for (int i = 0; i < mdhip_ctx::kFwdRing; ++i)
         for (int k = 0; k < 2; ++k)
@@ -1255,8 +1274,35 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     ctx->cur_A = num_anchors_for(ctx, h, w);
     ctx->pred_cur ^= 1;
     ctx->pred_off = ctx->pred_offs[ctx->pred_cur];
-    for (Op& op : ctx->ops)
-        if (int rc = run_op(ctx, op, n, h, w, s)) return rc;
+    const bool use_graph = (ctx->graph_mode == 1 || (ctx->graph_mode == 2 && n <= ctx->graph_max_n)) && !ctx->calibrating;
+    bool launched = false;
+    if (use_graph) {
+        mdhip_ctx::GraphSlot& g = ctx->graphs[std::make_tuple(n, h, w, ctx->pred_cur)];
+        if (g.exec) {
+            HIP_TRY(ctx, hipGraphLaunch(g.exec, s));
+            launched = true;
+        } else if (++g.seen >= 2) {
+            // the first forward of a shape runs eagerly (it settles the tile choices: a stale table entry is replaced on
+            // its first failing launch); the second is captured on an internal stream and replayed from then on
+            if (!ctx->capture_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->capture_stream, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipStreamBeginCapture(ctx->capture_stream, hipStreamCaptureModeThreadLocal));
+            int rc = MDHIP_OK;
+            for (Op& op : ctx->ops)
+                if ((rc = run_op(ctx, op, n, h, w, ctx->capture_stream)) != MDHIP_OK) break;
+            hipGraph_t graph = nullptr;
+            const hipError_t ee = hipStreamEndCapture(ctx->capture_stream, &graph);
+            if (rc != MDHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            HIP_TRY(ctx, ee);
+            const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            HIP_TRY(ctx, ei);
+            HIP_TRY(ctx, hipGraphLaunch(g.exec, s));
+            launched = true;
+        }
+    }
+    if (!launched)
+        for (Op& op : ctx->ops)
+            if (int rc = run_op(ctx, op, n, h, w, s)) return rc;
     if (ctx->time_forward) {
         HIP_TRY(ctx, hipEventRecord(ctx->fwd_ev[slot][1], s));
         ++ctx->fwd_count;
@@ -1661,12 +1707,22 @@ int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n) {
             return fail(ctx, MDHIP_EINVAL, "tuned entry %d: cfg %d outside [0,%d)", i, entries[i].cfg, conv_num_cfgs());
     ctx->tuned.assign(entries, entries + n);
     for (Op& op : ctx->ops) op.memo_cfg = -1;
+    drop_graphs(ctx);
     return MDHIP_OK;
 }
 
 int mdhip_set_fuse(mdhip_ctx* ctx, int on) {
     if (!ctx) return MDHIP_EINVAL;
     ctx->fuse_enabled = on != 0;
+    drop_graphs(ctx);
+    return MDHIP_OK;
+}
+
+int mdhip_set_graph(mdhip_ctx* ctx, int mode, int max_n) {
+    if (!ctx || mode < 0 || mode > 2) return MDHIP_EINVAL;
+    ctx->graph_mode = mode;
+    if (max_n > 0) ctx->graph_max_n = max_n;
+    if (mode == 0) drop_graphs(ctx);
     return MDHIP_OK;
 }
 
@@ -1675,6 +1731,7 @@ int mdhip_set_op_cfg(mdhip_ctx* ctx, int op, int cfg) {
     if (ctx->ops[op].kind != OP_CONV) return fail(ctx, MDHIP_EINVAL, "op %d is not a conv", op);
     if (cfg < -1 || cfg >= conv_num_cfgs()) return fail(ctx, MDHIP_EINVAL, "cfg %d outside [-1,%d)", cfg, conv_num_cfgs());
     ctx->ops[op].forced_cfg = cfg;
+    drop_graphs(ctx);
     return MDHIP_OK;
 }
 

@@ -73,7 +73,7 @@ class HIPDetector:
         model_path: a YOLOv5 .pt checkpoint (md_v5a.0.0.pt ...), a YoloWeights object, or the
         string 'synthetic[:yaml_name[:seed]]' for seeded weights on the MDv5 topology.
         detector_options keys honoured: force_cpu (must be false), use_model_native_classes,
-        compatibility_mode, preprocess_only, device, batch_size, max_image_size, dtype.
+        compatibility_mode, preprocess_only, device, batch_size, max_image_size, dtype, hip_graph ('auto' | 'on' | 'off').
         dtype: storage type of activations and packed weights (accumulation is fp32 either way).  Default 'fp16':
         |d conf| against the fp32 evaluation the reference performs stays below the reference's own bar between
         environments (0.005-0.01, md_tests.py:96-100,1779) with an 8x margin on every model measured
@@ -166,6 +166,9 @@ class HIPDetector:
         self._ctx = HipContext(weights, device=_device_ordinal(device), dtype=opts.get('dtype') or DEFAULT_DTYPE,
                                max_batch=self.max_batch, max_h=max_size, max_w=max_size)
         self.model = self._ctx
+        # launch plumbing, off by default: replaying the forward from a captured graph ('on'; 'auto' = batches <= 8) was
+        # measured and changes nothing -- at batch 1 .. 8 the step is bound by its kernels, not by their launches
+        self._ctx.set_graph(opts.get('hip_graph', 'off'))
         if fp8_scales:
             self._ctx.set_fp8_scales([float(v) for v in fp8_scales])
 

@@ -286,6 +286,12 @@ class HipContext:
         """fused bottleneck launches on (default) / off (the 1x1 and the 3x3 as two launches: same bits)"""
         self._check(self.lib.mdhip_set_fuse(self.h, 1 if on else 0), 'mdhip_set_fuse')
 
+    def set_graph(self, mode, max_n=0):
+        """graph replay of forward(): 0 / False = off, 1 / True = every forward, 2 / 'auto' = forwards of at most max_n
+        images (default 8); same kernels and arguments, bit-identical results (include/mdhip.h: mdhip_set_graph)"""
+        mode = {'off': 0, 'on': 1, 'auto': 2, False: 0, True: 1}.get(mode, mode)
+        self._check(self.lib.mdhip_set_graph(self.h, int(mode), int(max_n)), 'mdhip_set_graph')
+
     def op_supports_cfg(self, op, cfg):
         return self.lib.mdhip_op_supports_cfg(self.h, int(op), int(cfg)) == 1
 
