@@ -27,6 +27,12 @@
 //     DMA   weight slab of step+2 -> stage cur ; in steps s = 0, 1: pieces of the NEXT run
 //     read  X' (k 0..31 of step+1)                                  } interleaved
 //     mfma  Y                                                       }
+//
+// The two waves of a SIMD run this between the same barriers, so whatever sits between two MFMA chunks is
+// matrix-pipe idle time: a DMA piece is issued with 3-4 instructions (weights: lane offset fixed, step and
+// piece in the scalar offset; run pieces: addressed from the tensor's first byte, the descriptor's range check
+// zeroes what lies outside the batch), the tap select of the next step is pinned in the first half, and the
+// epilogue goes through buffer instructions with one 32-bit offset per lane (DESIGN.md section 5 [r3b]).
 
 #include <algorithm>
 #include <type_traits>
@@ -276,7 +282,7 @@ conv_v5_kernel(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- epilogue (as conv_v2: scalar bias, pixel-row order, 16-byte stores) --------------------------
+    // ---- epilogue (bias staged in LDS, pixel-row order, packed SiLU, 16-byte buffer stores) ----------
     const int q4 = lane >> 4;
     auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t, auto act_t) __attribute__((always_inline)) {
         // (x * r and the residual add stay two roundings -- as in every other kernel family, where a select on the
