@@ -69,6 +69,10 @@ def parse_args():
                     help='NMS + D2H of step i on their own stream next to the forward of step i+1 (round 1); default: on the '
                          'compute stream behind the forward')
     ap.add_argument('--profile-out', default=None, help='write per-op timings (json) here')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help='skip the short legs of the other BASELINE configurations (extra_configs: fp8 batch 64, 1080p video '
+                         'frames, 4:3 real shape, fp16 storage); they only run with the default headline workload on one GPU')
+    ap.add_argument('--extra-steps', type=int, default=10)
     return ap.parse_args()
 
 
@@ -117,6 +121,198 @@ def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
     return res
 
 
+class Workload:
+    """One bench workload on one GPU: a context, synthetic uint8 batches resident in HBM, and the software pipeline of a
+    step (letterbox -> conv stack -> decode -> NMS -> D2H -> host formatting of the previous step's detections)."""
+
+    RING = 16
+
+    def __init__(self, torch, weights, dtype, B, S, src, threshold, device, seed_base=0, n_batches=8, host_fed=False,
+                 nms_own_stream=False, graph='off', no_table=False):
+        from megadetector_amd.hip_backend import HipContext
+        from megadetector_amd.postprocess import letterbox_geometry
+        self.torch, self.B, self.S, self.threshold, self.dtype = torch, B, S, threshold, dtype
+        self.host_fed, self.nms_own_stream = host_fed, nms_own_stream
+        H0, W0 = (int(v) for v in src.lower().split('x')) if src else (S, S)
+        lb = letterbox_geometry((H0, W0), new_shape=S, stride=64, auto=True, scaleup=True)
+        self.H0, self.W0 = H0, W0
+        self.Hn, self.Wn = lb['out_hw']             # network input (letterboxed) shape
+        self.ctx = ctx = HipContext(weights, device=device, dtype=dtype, max_batch=B, max_h=S, max_w=S)
+        ctx.set_graph(graph)
+        # measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json) are loaded by HipContext
+        if no_table:
+            ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
+        # synthetic uint8 RGB batches, resident in HBM before the timed region (SURVEY.md 8(d): K >= 8 distinct, cycled)
+        self.n_batches = n_batches
+        gen = torch.Generator(device='cuda')
+        batches = []
+        for i in range(n_batches):
+            gen.manual_seed(seed_base + i)
+            batches.append(torch.randint(0, 256, (B, H0, W0, 3), dtype=torch.uint8, device='cuda', generator=gen))
+        self.geoms = [(H0, W0, lb['new_unpad'][1], lb['new_unpad'][0], lb['top'], lb['left'])] * B
+        self.ptr_lists = [[int(b[i].data_ptr()) for i in range(B)] for b in batches]
+        # everything is enqueued on one non-blocking stream (the legacy null stream synchronises implicitly
+        # with every other blocking stream and measured ~1.5 ms per step slower)
+        self.comp_s = torch.cuda.Stream()
+        self.compute_stream = self.comp_s.cuda_stream
+        # --nms-own-stream: NMS + D2H of step i on their own stream, next to the forward of step i+1 (the library
+        # alternates between two prediction buffers); ordered with events
+        self.nms_s = torch.cuda.Stream()
+        self.fwd_done = [torch.cuda.Event() for _ in range(4)]
+        self.nms_done = [None] * 4
+        # live per-stage timing (roofline.stages): event pairs on the stream each stage is launched on
+        self.ev_pre = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(self.RING)]
+        self.ev_nms = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(self.RING)]
+        self.stage_live = {'on': False, 'steps': []}
+        self.dev_ptrs = None
+        if host_fed:
+            # PCIe-inclusive variant: the batches live in pinned host memory; every step copies its batch
+            # into one of two device buffers on a copy stream while the previous step computes
+            self.host_batches = [b.cpu().pin_memory() for b in batches]
+            self.dev_in = [torch.empty_like(batches[0]) for _ in range(2)]
+            self.dev_ptrs = [[int(d[i].data_ptr()) for i in range(B)] for d in self.dev_in]
+            self.copy_s = torch.cuda.Stream()
+            self.copied = [torch.cuda.Event() for _ in range(2)]
+            self.consumed = [torch.cuda.Event() for _ in range(2)]
+            batches = None
+        self.batches = batches
+        torch.cuda.synchronize()
+
+    def prepare(self):
+        """fp8 mode: static activation scales from the first synthetic batch (mdhip_calibrate), before anything is timed"""
+        if self.dtype != 'fp8':
+            return
+        ctx = self.ctx
+        if self.host_fed:
+            self.dev_in[0].copy_(self.host_batches[0])
+            self.torch.cuda.synchronize()
+            ctx.preprocess(self.dev_ptrs[0], self.geoms, self.Hn, self.Wn, stream=self.compute_stream)
+        else:
+            ctx.preprocess(self.ptr_lists[0], self.geoms, self.Hn, self.Wn, stream=self.compute_stream)
+        ctx.calibrate(self.B, self.Hn, self.Wn, stream=self.compute_stream)
+
+    # Software pipeline: the GPU work of step i (preprocess -> forward -> NMS -> D2H into a pinned
+    # slot) is enqueued asynchronously, then the host formats the detections of step i-1 while the
+    # GPU runs step i.  Every step's results are fully formatted inside the timed region.
+    def forward_and_nms(self, i):
+        torch, ctx, comp_s = self.torch, self.ctx, self.comp_s
+        k = i % 4
+        if self.nms_done[(i - 2) % 4] is not None:
+            comp_s.wait_event(self.nms_done[(i - 2) % 4])      # the prediction buffer this forward overwrites has been consumed
+        ctx.forward(self.B, self.Hn, self.Wn, stream=self.compute_stream)
+        ns = self.nms_s if self.nms_own_stream else comp_s
+        if self.nms_own_stream:
+            self.fwd_done[k].record(comp_s)
+            self.nms_s.wait_event(self.fwd_done[k])
+        if self.stage_live['on']:
+            self.ev_nms[i % self.RING][0].record(ns)
+        ctx.nms_enqueue(self.B, self.threshold, 0.45, 300, slot=k, stream=ns.cuda_stream)
+        if self.stage_live['on']:
+            self.ev_nms[i % self.RING][1].record(ns)
+        ev = torch.cuda.Event()
+        ev.record(ns)
+        self.nms_done[k] = ev
+
+    def enqueue(self, i):
+        torch, ctx, comp_s = self.torch, self.ctx, self.comp_s
+        if self.host_fed:
+            k = i % 2
+            with torch.cuda.stream(self.copy_s):
+                if i >= 2:
+                    self.copy_s.wait_event(self.consumed[k])          # the letterbox kernel of step i-2 has read this buffer
+                self.dev_in[k].copy_(self.host_batches[i % self.n_batches], non_blocking=True)
+                self.copied[k].record(self.copy_s)
+            comp_s.wait_event(self.copied[k])
+            ctx.preprocess(self.dev_ptrs[k], self.geoms, self.Hn, self.Wn, stream=self.compute_stream)
+            self.consumed[k].record(comp_s)
+            self.forward_and_nms(i)
+            return
+        if self.stage_live['on']:
+            self.ev_pre[i % self.RING][0].record(comp_s)
+        ctx.preprocess(self.ptr_lists[i % self.n_batches], self.geoms, self.Hn, self.Wn, stream=self.compute_stream)
+        if self.stage_live['on']:
+            self.ev_pre[i % self.RING][1].record(comp_s)
+            self.stage_live['steps'].append(i)
+        self.forward_and_nms(i)
+
+    def collect(self, i):
+        from megadetector_amd.postprocess import format_detections
+        det, counts = self.ctx.nms_wait(slot=i % 4)
+        return [format_detections(det[b, :counts[b]], (self.Hn, self.Wn), (self.H0, self.W0, 3), (self.H0, self.W0, 3),
+                                  self.threshold) for b in range(self.B)]
+
+    def run(self, n_steps):
+        # two steps are kept queued on the GPU behind the running one, so that a slow moment of the host
+        # thread (formatting, a descheduled process) does not leave the GPU idle
+        last = None
+        depth = 2
+        for i in range(n_steps):
+            self.enqueue(i)
+            if i >= depth:
+                last = self.collect(i - depth)
+        for i in range(max(0, n_steps - depth), n_steps):
+            last = self.collect(i)
+        return last
+
+    def conv_roofline(self, fwd_ms):
+        """(achieved TFLOP/s, peak TFLOP/s, share of the FLOPs on e4m3 operands) of the conv stack for a forward of
+        fwd_ms: algorithmic conv FLOPs of the ops of the last forward; every launch priced at its own MFMA peak"""
+        ctx = self.ctx
+        conv = [o for o in ctx.op_infos() if o['kind'] == 0]
+        flops = sum(o['flops'] for o in conv)
+        op_peak = lambda o: PEAK_FP8_TFLOPS if ctx.conv_cfg_name(o['cfg']).startswith('f8:') else PEAK_BF16_TFLOPS
+        peak = flops / sum(o['flops'] / op_peak(o) for o in conv)
+        f8 = sum(o['flops'] for o in conv if op_peak(o) == PEAK_FP8_TFLOPS) / flops
+        return flops / (fwd_ms * 1e-3) / 1e12, peak, f8, flops
+
+    def close(self):
+        self.torch.cuda.synchronize()
+        self.ctx.close()
+        self.batches = None
+
+
+# bench.py's default invocation also measures, after the timed region of the headline workload (BASELINE configs[1]),
+# every other BASELINE configuration that fits one GPU -- short legs, reported under "extra_configs", never `value`
+EXTRA_LEGS = [
+    # key,            dtype,  batch, source HxW,  what
+    ('fp8_b64',       'fp8',  64, None,        'BASELINE configs[4]: fp8 (bottleneck 3x3 convs on e4m3 operands), 1280x1280, batch 64'),
+    ('video_1080p',   'bf16', 32, '1080x1920', 'BASELINE configs[3] on one GPU: 1080x1920 video frames -> 768x1280 letterbox, batch 32'),
+    ('real_4x3',      'bf16', 32, '1536x2048', 'SURVEY 8(d) real-shape variant: 1536x2048 camera-trap images -> 960x1280 letterbox, batch 32'),
+    ('fp16_default',  'fp16', 32, None,        "fp16 storage (the detector's default dtype), 1280x1280, batch 32"),
+]
+
+
+def extra_leg(torch, weights, key, dtype, B, src, what, S, threshold, device, steps, warmup):
+    t_start = time.perf_counter()
+    wl = Workload(torch, weights, dtype, B, S, src, threshold, device, seed_base=7000, n_batches=2)
+    try:
+        wl.prepare()
+        wl.run(2)
+        wl.run(warmup)
+        wl.ctx.time_forwards(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wl.run(steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        fwd = wl.ctx.forward_times(min(steps, 64))
+        wl.ctx.time_forwards(False)
+        fwd_ms = float(np.mean(fwd))
+        achieved, peak, f8, flops = wl.conv_roofline(fwd_ms)
+        return {
+            'workload': '{} ({}x{} letterbox, {:.2f} GFLOP/image, uint8 inputs resident in HBM, NMS threshold {})'.format(
+                what, wl.Hn, wl.Wn, flops / B / 1e9, threshold),
+            'value': round(B * steps / elapsed, 2), 'unit': 'images/s', 'ms_per_step': round(elapsed / steps * 1e3, 3),
+            'steps': steps, 'warmup': warmup, 'dtype': dtype, 'batch': B,
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                         'frac': round(achieved / peak, 4), 'kernel_ms_per_step': round(fwd_ms, 3),
+                         'e4m3_flop_share': round(f8, 4)},
+            'leg_seconds': round(time.perf_counter() - t_start, 2),
+        }
+    finally:
+        wl.close()
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', '0'))
@@ -134,7 +330,7 @@ def main():
     # one rank per GPU: CPUs of the GPU's NUMA node, disjoint from the other ranks' (the host thread formats 2.8 ms of
     # detections per step and keeps the queue fed; SURVEY.md 8(e) "scaling limiter")
     from megadetector_amd import placement
-    pinned_cpus = placement.pin_worker(local_rank, 1 if one_gpu else world, verbose=False)
+    pinned_cpus = placement.pin_worker(local_rank, 1 if one_gpu else int(os.environ.get('LOCAL_WORLD_SIZE', world)), verbose=False)
     if world > 1:                                              # stdout carries the one JSON line and nothing else
         print('rank {}: {} CPUs{}'.format(rank, len(pinned_cpus), ' ({}..{})'.format(pinned_cpus[0], pinned_cpus[-1])
                                           if pinned_cpus else ''), file=sys.stderr)
@@ -149,116 +345,18 @@ def main():
                                     device_id=torch.device('cuda', local_rank))
 
     from megadetector_amd import weights_io, yolo_yaml
-    from megadetector_amd.hip_backend import HipContext
-    from megadetector_amd.postprocess import format_detections, letterbox_geometry
+    from megadetector_amd.postprocess import format_detections
 
     B, S = args.batch, args.size
-    H0, W0 = (int(v) for v in args.src.lower().split('x')) if args.src else (S, S)
-    lb = letterbox_geometry((H0, W0), new_shape=S, stride=64, auto=True, scaleup=True)
-    Hn, Wn = lb['out_hw']                       # network input (letterboxed) shape
     yaml = getattr(yolo_yaml, args.model)
     weights = weights_io.synthetic_weights(yaml, seed=0)
-    ctx = HipContext(weights, device=local_rank, dtype=args.dtype, max_batch=B, max_h=S, max_w=S)
-    ctx.set_graph(args.graph)
-
-    # measured tile choices (tools/autotune.py -> megadetector_amd/tuned_cfgs.json) are loaded by HipContext
-    if args.no_table:
-        ctx.lib.mdhip_set_tuned(ctx.h, None, 0)
-
-    # synthetic uint8 RGB batches, resident in HBM before the timed region
-    n_batches = 8                               # K >= 8 distinct batches, cycled
-    gen = torch.Generator(device='cuda')
-    batches = []
-    for i in range(n_batches):
-        gen.manual_seed(1000 * rank + i)
-        batches.append(torch.randint(0, 256, (B, H0, W0, 3), dtype=torch.uint8, device='cuda', generator=gen))
-    geoms = [(H0, W0, lb['new_unpad'][1], lb['new_unpad'][0], lb['top'], lb['left'])] * B
-    ptr_lists = [[int(b[i].data_ptr()) for i in range(B)] for b in batches]
-    # everything is enqueued on one non-blocking stream (the legacy null stream synchronises implicitly
-    # with every other blocking stream and measured ~1.5 ms per step slower)
-    comp_s = torch.cuda.Stream()
-    compute_stream = comp_s.cuda_stream
-    # NMS + D2H of step i run on their own stream, next to the forward of step i+1 (the library alternates between
-    # two prediction buffers); ordered with events
-    nms_s = torch.cuda.Stream()
-    fwd_done = [torch.cuda.Event() for _ in range(4)]
-    nms_done = [None] * 4
-    # live per-stage timing (roofline.stages): event pairs on the stream each stage is launched on
-    RING = 16
-    ev_pre = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(RING)]
-    ev_nms = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(RING)]
-    stage_live = {'on': False, 'steps': []}
-    if args.host_fed:
-        # PCIe-inclusive variant: the batches live in pinned host memory; every step copies its batch
-        # into one of two device buffers on a copy stream while the previous step computes
-        host_batches = [b.cpu().pin_memory() for b in batches]
-        dev_in = [torch.empty_like(batches[0]) for _ in range(2)]
-        dev_ptrs = [[int(d[i].data_ptr()) for i in range(B)] for d in dev_in]
-        copy_s = torch.cuda.Stream()
-        copied = [torch.cuda.Event() for _ in range(2)]
-        consumed = [torch.cuda.Event() for _ in range(2)]
-        del batches
-    torch.cuda.synchronize()
-
-    # Software pipeline: the GPU work of step i (preprocess -> forward -> NMS -> D2H into a pinned
-    # slot) is enqueued asynchronously, then the host formats the detections of step i-1 while the
-    # GPU runs step i.  Every step's results are fully formatted inside the timed region.
-    def forward_and_nms(i):
-        k = i % 4
-        if nms_done[(i - 2) % 4] is not None:
-            comp_s.wait_event(nms_done[(i - 2) % 4])      # the prediction buffer this forward overwrites has been consumed
-        ctx.forward(B, Hn, Wn, stream=compute_stream)
-        ns = nms_s if args.nms_own_stream else comp_s
-        if args.nms_own_stream:
-            fwd_done[k].record(comp_s)
-            nms_s.wait_event(fwd_done[k])
-        if stage_live['on']:
-            ev_nms[i % RING][0].record(ns)
-        ctx.nms_enqueue(B, args.threshold, 0.45, 300, slot=k, stream=ns.cuda_stream)
-        if stage_live['on']:
-            ev_nms[i % RING][1].record(ns)
-        ev = torch.cuda.Event()
-        ev.record(ns)
-        nms_done[k] = ev
-
-    def enqueue(i):
-        if args.host_fed:
-            k = i % 2
-            with torch.cuda.stream(copy_s):
-                if i >= 2:
-                    copy_s.wait_event(consumed[k])          # the letterbox kernel of step i-2 has read this buffer
-                dev_in[k].copy_(host_batches[i % n_batches], non_blocking=True)
-                copied[k].record(copy_s)
-            comp_s.wait_event(copied[k])
-            ctx.preprocess(dev_ptrs[k], geoms, Hn, Wn, stream=compute_stream)
-            consumed[k].record(comp_s)
-            forward_and_nms(i)
-            return
-        if stage_live['on']:
-            ev_pre[i % RING][0].record(comp_s)
-        ctx.preprocess(ptr_lists[i % n_batches], geoms, Hn, Wn, stream=compute_stream)
-        if stage_live['on']:
-            ev_pre[i % RING][1].record(comp_s)
-            stage_live['steps'].append(i)
-        forward_and_nms(i)
-
-    def collect(i):
-        det, counts = ctx.nms_wait(slot=i % 4)
-        return [format_detections(det[b, :counts[b]], (Hn, Wn), (H0, W0, 3), (H0, W0, 3), args.threshold)
-                for b in range(B)]
-
-    def run(n_steps):
-        # two steps are kept queued on the GPU behind the running one, so that a slow moment of the host
-        # thread (formatting, a descheduled process) does not leave the GPU idle
-        last = None
-        depth = 2
-        for i in range(n_steps):
-            enqueue(i)
-            if i >= depth:
-                last = collect(i - depth)
-        for i in range(max(0, n_steps - depth), n_steps):
-            last = collect(i)
-        return last
+    wl = Workload(torch, weights, args.dtype, B, S, args.src, args.threshold, local_rank, seed_base=1000 * rank,
+                  host_fed=args.host_fed, nms_own_stream=args.nms_own_stream, graph=args.graph, no_table=args.no_table)
+    ctx, run, stage_live = wl.ctx, wl.run, wl.stage_live
+    H0, W0, Hn, Wn = wl.H0, wl.W0, wl.Hn, wl.Wn
+    geoms, ptr_lists, compute_stream = wl.geoms, wl.ptr_lists, wl.compute_stream
+    dev_ptrs = wl.dev_ptrs
+    ev_pre, ev_nms, RING = wl.ev_pre, wl.ev_nms, wl.RING
 
     def barrier():
         torch.cuda.synchronize()
@@ -266,14 +364,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.dtype == 'fp8':
-        # static activation scales from the first synthetic batch (mdhip_calibrate), before anything is timed
-        ctx.preprocess(ptr_lists[0] if not args.host_fed else dev_ptrs[0], geoms, Hn, Wn, stream=compute_stream)
-        if args.host_fed:
-            dev_in[0].copy_(host_batches[0])
-            torch.cuda.synchronize()
-            ctx.preprocess(dev_ptrs[0], geoms, Hn, Wn, stream=compute_stream)
-        ctx.calibrate(B, Hn, Wn, stream=compute_stream)
+    wl.prepare()                # fp8: static activation scales from the first synthetic batch (mdhip_calibrate), before anything is timed
     run(2)                      # initialisation (first-touch of every buffer and code path), not a warm-up step
     run(args.warmup)
     # live roofline measurement: a HIP event pair on the launch stream around the conv stack of every
@@ -353,7 +444,7 @@ def main():
         fwd_ms = float(np.mean(fwd_ms_live)) if len(fwd_ms_live) else float(ms.sum())
         achieved = conv_flops / (fwd_ms * 1e-3) / 1e12
         # HBM bytes per step from the PMC counters: two separate `rocprofv3 --pmc` passes of THIS command
-        # (FETCH_SIZE, WRITE_SIZE; tools/gpu_round.sh traffic -> tools/hbm_traffic.py), committed under profiles/.
+        # (FETCH_SIZE, WRITE_SIZE; tools/gpu_session.sh traffic -> tools/hbm_traffic.py), committed under profiles/.
         # It is read from the newest committed measurement of this workload, not measured in this run (counters
         # cannot be collected from inside the process); `traffic_source` says which file.
         traffic, traffic_source = None, None
@@ -464,6 +555,19 @@ def main():
                                 gbps=(o['bytes'] / (ms[o['op']] * 1e-3) / 1e9 if ms[o['op']] > 0 else 0.0))
                            for o in infos], f, indent=1)
 
+    extra = None
+    default_workload = (args.dtype == 'bf16' and B == 32 and not args.src and not args.host_fed and args.model == 'YOLOV5X6_MD'
+                        and S == 1280 and not args.no_table)
+    if rank == 0 and world == 1 and default_workload and not args.lean and not args.no_extra_configs:
+        wl.close()                                   # the headline context's arena goes back before the legs allocate theirs
+        extra = {}
+        for key, dt, b, src, what in EXTRA_LEGS:
+            try:
+                extra[key] = extra_leg(torch, weights, key, dt, b, src, what, S, args.threshold, local_rank,
+                                       steps=args.extra_steps, warmup=3)
+            except Exception as e:                   # a failing leg must not cost the headline line
+                extra[key] = {'error': '{}: {}'.format(type(e).__name__, e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(weights, S, args.threshold, args.cpu_seconds, single_thread=not args.no_cpu_single_thread)
@@ -496,13 +600,14 @@ def main():
             'roofline': roof,
             'cpu_baseline': cpu,
             'stages': stages,
+            'extra_configs': extra,
             'per_rank_images_per_s': per_rank,
         }
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    wl.close()
 
 
 if __name__ == '__main__':

@@ -200,6 +200,8 @@ conv_v2_kernel(const ConvArgs p) {
         c8 = jj; ts = 0; tapbit = 1; tapoff = (unsigned)jj * 16u;
     };
 
+    // (PW) this lane's 16-byte chunk of the last K slab lies past the last input channel
+    [[maybe_unused]] const bool pw_tail_bad = (p.C8 & 7) != 0 && jj >= (p.C8 & 7);
     // the loader moves on by one slab (branch-free inside a tile)
     auto advance = [&]() __attribute__((always_inline)) {
         if (++l_kt == KT) {
@@ -213,6 +215,17 @@ conv_v2_kernel(const ConvArgs p) {
                 init_tile(l_tile);
             }
         } else {
+            if constexpr (PW) {
+                // the tensor's last K slab when C_in is no multiple of 64 (C8 % 8 != 0: 80, 160, 480 channels): its
+                // chunks past the last channel would read the NEXT pixel's first channels (or, in a channel slice of a
+                // wider buffer, the neighbouring tensor's) against zero weights -- 0 * Inf / NaN would poison every output
+                // channel of the pixel.  Those lanes read zeros through the range check instead; init_tile restores
+                // the offsets with the next tile.
+                if (l_kt == KT - 1 && pw_tail_bad) {
+#pragma unroll
+                    for (int i = 0; i < A_PER; ++i) a_off[i] = kOOB;
+                }
+            }
             c8 += 8;
             tapoff += 128u;
             const bool w = c8 >= p.C8;

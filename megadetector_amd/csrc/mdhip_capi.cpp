@@ -158,8 +158,11 @@ struct mdhip_ctx {
     int graph_mode = 0;                                   // 0 = off, 1 = on, 2 = on for batches <= graph_max_n
     int graph_max_n = 8;
     hipStream_t capture_stream = nullptr;
-    struct GraphSlot { hipGraphExec_t exec = nullptr; int seen = 0; };
+    // `disabled`: capture or instantiation failed once for this shape -- it runs eagerly from then on; `last_use`: LRU stamp
+    struct GraphSlot { hipGraphExec_t exec = nullptr; int seen = 0; bool disabled = false; long long last_use = 0; };
     std::map<std::tuple<int, int, int, int>, GraphSlot> graphs;
+    static constexpr int kMaxGraphs = 32;                 // cached executables (letterbox shapes x batch sizes x 2 buffers)
+    long long graph_clock = 0;
 };
 
 namespace {
@@ -174,11 +177,29 @@ int fail(mdhip_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
-// every call that changes what a forward launches drops the captured graphs
+// every call that changes what a forward launches drops the captured graphs (after the device has finished with them: an
+// executable may still be in flight on the caller's stream)
 void drop_graphs(mdhip_ctx* ctx) {
+    bool any = false;
+    for (auto& kv : ctx->graphs) any |= kv.second.exec != nullptr;
+    if (any) (void)hipDeviceSynchronize();
     for (auto& kv : ctx->graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     ctx->graphs.clear();
+}
+
+// room for one more cached graph: the least recently used executable goes (its stream work is waited for first)
+void evict_graph_if_full(mdhip_ctx* ctx) {
+    int live = 0;
+    for (auto& kv : ctx->graphs) live += kv.second.exec != nullptr;
+    if (live < mdhip_ctx::kMaxGraphs) return;
+    auto victim = ctx->graphs.end();
+    for (auto it = ctx->graphs.begin(); it != ctx->graphs.end(); ++it)
+        if (it->second.exec && (victim == ctx->graphs.end() || it->second.last_use < victim->second.last_use)) victim = it;
+    if (victim == ctx->graphs.end()) return;
+    (void)hipDeviceSynchronize();
+    (void)hipGraphExecDestroy(victim->second.exec);
+    ctx->graphs.erase(victim);
 }
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -1149,7 +1170,13 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
         CREATE_TRY(hipHostMalloc((void**)&ctx->nms_host_cnt[i], (size_t)max_batch * 4, hipHostMallocDefault));
         CREATE_TRY(hipEventCreateWithFlags(&ctx->nms_ev[i], hipEventDisableTiming));
     }
-    CREATE_TRY(hipMemset(ctx->arena, 0, std::min(ctx->arena_bytes, (size_t)1 << 20)));
+    // The whole arena starts as zeros: no kernel's result may depend on memory nobody wrote (K-slab tails against zero
+    // weights, pad channels, halo rows of a neighbouring tensor).  MDHIP_ARENA_POISON=1 (tests) fills it with 0xFF bytes
+    // instead -- NaN in bf16, fp16 and fp32 -- so that any such read shows up as NaN in the output.
+    {
+        const char* pz = getenv("MDHIP_ARENA_POISON");
+        CREATE_TRY(hipMemset(ctx->arena, (pz && atoi(pz) != 0) ? 0xff : 0, ctx->arena_bytes));
+    }
     if (has_detect)
         CREATE_TRY(hipMemcpy(ctx->warena + ctx->anchors_off, model->anchors_px, (size_t)ctx->nl * ctx->na * 2 * 4, hipMemcpyHostToDevice));
     for (size_t i = 0; i < ctx->packed.size(); ++i) {
@@ -1278,26 +1305,36 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     bool launched = false;
     if (use_graph) {
         mdhip_ctx::GraphSlot& g = ctx->graphs[std::make_tuple(n, h, w, ctx->pred_cur)];
+        g.last_use = ++ctx->graph_clock;
         if (g.exec) {
             HIP_TRY(ctx, hipGraphLaunch(g.exec, s));
             launched = true;
-        } else if (++g.seen >= 2) {
+        } else if (!g.disabled && ++g.seen >= 2) {
             // the first forward of a shape runs eagerly (it settles the tile choices: a stale table entry is replaced on
-            // its first failing launch); the second is captured on an internal stream and replayed from then on
+            // its first failing launch); the second is captured on an internal stream and replayed from then on.  A
+            // capture or instantiation that fails disables replay for this shape: the eager path below just worked.
             if (!ctx->capture_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->capture_stream, hipStreamNonBlocking));
-            HIP_TRY(ctx, hipStreamBeginCapture(ctx->capture_stream, hipStreamCaptureModeThreadLocal));
-            int rc = MDHIP_OK;
-            for (Op& op : ctx->ops)
-                if ((rc = run_op(ctx, op, n, h, w, ctx->capture_stream)) != MDHIP_OK) break;
             hipGraph_t graph = nullptr;
-            const hipError_t ee = hipStreamEndCapture(ctx->capture_stream, &graph);
-            if (rc != MDHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            HIP_TRY(ctx, ee);
-            const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            HIP_TRY(ctx, ei);
-            HIP_TRY(ctx, hipGraphLaunch(g.exec, s));
-            launched = true;
+            hipGraphExec_t exec = nullptr;
+            bool ok = hipStreamBeginCapture(ctx->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                for (Op& op : ctx->ops)
+                    if (run_op(ctx, op, n, h, w, ctx->capture_stream) != MDHIP_OK) { ok = false; break; }
+                ok = (hipStreamEndCapture(ctx->capture_stream, &graph) == hipSuccess) && ok && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec != nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok) {
+                (void)hipGetLastError();
+                if (exec) (void)hipGraphExecDestroy(exec);
+                g.disabled = true;
+            } else {
+                // (evict_graph_if_full may erase other map entries: std::map references to `g` stay valid)
+                evict_graph_if_full(ctx);
+                g.exec = exec;
+                HIP_TRY(ctx, hipGraphLaunch(g.exec, s));
+                launched = true;
+            }
         }
     }
     if (!launched)

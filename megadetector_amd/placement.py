@@ -132,7 +132,18 @@ def pin_worker(gpu, n_gpus, topology=None, verbose=True):
     topology = topology or read_topology(n_gpus)
     cpus = plan(n_gpus, topology)[gpu]
     try:
-        os.sched_setaffinity(0, cpus)
+        # every thread of the process, not only the caller: sched_setaffinity(0, ...) pins the calling THREAD on Linux,
+        # and the runtime threads that torch / numpy / the HIP runtime started while importing would keep the full mask
+        tids = [0]
+        try:
+            tids += [int(t) for t in os.listdir('/proc/self/task')]
+        except OSError:
+            pass
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, cpus)
+            except ProcessLookupError:
+                pass                                   # a thread that ended in between
     except OSError as e:
         print('Warning: could not pin the worker of GPU {} to CPUs {}: {}'.format(gpu, cpus, e))
         return sorted(os.sched_getaffinity(0))

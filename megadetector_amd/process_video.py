@@ -329,7 +329,9 @@ def run_detector_on_videos_sharded(model_file, videos, n_gpus, detector_options=
     spawned process with its own detector (device cuda:g) and CPU set (placement.py); the result equals the
     one-process result.  `worker` replaces the shard process body in the CPU tests.
     """
-    from .run_detector_batch import run_spawned_shards
+    from .run_detector_batch import run_spawned_shards, require_saved_fp8_scales_for_shards
+    if n_gpus > 1:
+        require_saved_fp8_scales_for_shards(detector_options)
     shards = shard_videos(videos, n_gpus)
     args = [(model_file, [videos[i] for i in shards[g]], dict(detector_options or {}), dict(run_kwargs), n_gpus)
             for g in range(n_gpus)]

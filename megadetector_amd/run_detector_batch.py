@@ -696,6 +696,18 @@ def run_spawned_shards(target, shard_args, n_shards):
     return [got[g] for g in range(n_shards)]
 
 
+def require_saved_fp8_scales_for_shards(detector_options):
+    """A multi-GPU run (image shards here, video shards in process_video.py) in the fp8 mode must start from SAVED
+    activation scales: with fp8_calibrate_on_first_batch every shard would calibrate its e4m3 scales on its own first
+    batch (and race to write the same fp8_scales_file), so the same image would get different detections depending
+    on n_gpus and the shard it lands in."""
+    dopts = detector_options or {}
+    if str(dopts.get('dtype', '')).lower() == 'fp8' and not dopts.get('fp8_scales') and not (
+            dopts.get('fp8_scales_file') and os.path.isfile(dopts['fp8_scales_file'])):
+        raise ValueError("dtype 'fp8' on several GPUs needs saved scales (detector_options fp8_scales or an existing "
+                         "fp8_scales_file): calibrate once on one GPU first")
+
+
 def run_sharded(model_file, image_file_names, n_gpus, results=None, worker=None, **kwargs):
     """
     Runs load_and_run_detector_batch on n_gpus GPUs of one node: the image list is split
@@ -717,12 +729,7 @@ def run_sharded(model_file, image_file_names, n_gpus, results=None, worker=None,
     dopts = kwargs.get('detector_options') or {}
     if isinstance(dopts, (list, str)):
         dopts = parse_kvp_list(dopts)
-    if str(dopts.get('dtype', '')).lower() == 'fp8' and not dopts.get('fp8_scales') and not (
-            dopts.get('fp8_scales_file') and os.path.isfile(dopts['fp8_scales_file'])):
-        # every shard would calibrate its e4m3 scales on its own first batch: the same image would get different
-        # detections depending on n_gpus
-        raise ValueError("dtype 'fp8' on several GPUs needs saved scales (detector_options fp8_scales or an existing "
-                         "fp8_scales_file): calibrate once on one GPU first")
+    require_saved_fp8_scales_for_shards(dopts)
     ck = kwargs.get('checkpoint_path')
     if ck is not None and results and (kwargs.get('checkpoint_frequency') or -1) > 0:
         # The shards only know their own new results, and their `<ck>.shard<g>` files are about to be overwritten by

@@ -45,3 +45,17 @@ def test_sharded_fp8_run_needs_saved_scales(tmp_path):
     res = RDB.run_sharded('synthetic', files, 2, worker=_posting_worker,
                           detector_options=['dtype=fp8', 'fp8_scales=0.5;0.25'])
     assert len(res) == 3
+
+
+def test_sharded_fp8_video_run_needs_saved_scales(tmp_path):
+    """the multi-GPU VIDEO path has the same guard as run_sharded (every shard would otherwise calibrate on
+    its own first frames and race to replace the same fp8_scales_file)"""
+    from megadetector_amd import process_video as PV
+    videos = [('a.mp4', '/nonexistent/a.mp4'), ('b.mp4', '/nonexistent/b.mp4')]
+    for opts in ({'dtype': 'fp8'}, {'dtype': 'fp8', 'fp8_calibrate_on_first_batch': True,
+                                    'fp8_scales_file': str(tmp_path / 'not_yet.json')}):
+        with pytest.raises(ValueError, match='saved scales'):
+            PV.run_detector_on_videos_sharded('synthetic', videos, 2, detector_options=opts, worker=_never_called)
+        with pytest.raises(ValueError, match='saved scales'):
+            PV.process_videos('synthetic', '/nonexistent', str(tmp_path / 'out.json'), frame_sample=1, batch_size=2,
+                              n_gpus=2, detector_options=opts, videos=videos, shard_worker=_never_called)

@@ -126,7 +126,7 @@ def test_fp8_headline_topology_layers(forced_batch):
     `bench.py --dtype fp8 --batch 64` (BASELINE.json configs[4]) launches, asserted per op"""
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.hip_backend import HipContext
-    from test_gpu_headline import force_batch32_tiles, _ran_tiles
+    from test_gpu_headline import force_table_tiles, assert_forced_equal_benchmarked, _ran_tiles
     W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
     HH = WW = 640
     ctx = HipContext(W, device=0, dtype='fp8', max_batch=2, max_h=HH, max_w=WW)
@@ -140,8 +140,9 @@ def test_fp8_headline_topology_layers(forced_batch):
         forced = None
         if forced_batch is not None:
             ctx.forward(2, HH, WW)                 # (op_infos of a forward: geometry of every op)
-            forced = force_batch32_tiles(ctx, 2, HH, WW, batch=forced_batch)
+            forced = force_table_tiles(ctx, 2, HH, WW, batch=forced_batch, shape=(1280, 1280))
             assert len(forced) == 152, len(forced)
+            assert_forced_equal_benchmarked(ctx, forced, 'fp8', forced_batch, (1280, 1280))
         ctx.forward(2, HH, WW)
         if forced is not None:
             ran = _ran_tiles(ctx, forced)

@@ -5,10 +5,15 @@ against the oracle -- reference megadetector/detection/pytorch_detector.py:1313 
 module built at :957.  The toy networks of tests/test_gpu_parity.py never reach these shapes.
 
   * 640x640, two images: every layer against the storage-emulating oracle, with every conv forced to the tile the
-    table holds for batch 32 at 1280x1280 (the benchmarked launch configuration), and bit-identical to the tiles the
-    table picks on its own for this batch;
-  * 1280x1280, one image, through the detector seam: predictions against the oracle within the layer tolerances,
-    NMS + rescale + formatting exact on the HIP predictions;
+    table holds for THAT layer at batch 32 / 1280x1280 (exact match on the layer geometry and M = 32 x H_out x W_out;
+    the forced names are compared with the list recorded from the benchmarked forward on the GPU,
+    tests/golden/bench_tiles.json), and bit-identical to the tiles the table picks on its own for this batch;
+  * 1280x1280, one image, through the detector seam, the same exact tiles: EVERY LAYER and the predictions against
+    the oracle within the layer tolerances, NMS + rescale + formatting exact on the HIP predictions;
+  * the real letterbox shapes (pytorch_detector.py:1226-1233 groups a batch by processed shape): a 1080x1920 source
+    -> 768x1280 (BASELINE configs[3], video frames) and a 1536x2048 source -> 960x1280 (SURVEY 8(d) real-shape), one
+    image each through the detector seam with the batch-32 tiles of THAT shape: letterboxed input bit-exact, every
+    layer + predictions against the oracle, NMS / formatting exact on the HIP predictions;
   * the same at 640x640 for fp16 storage (the detector's default storage type) with its 8x tighter tolerances.
 
 Tolerances: tests/test_gpu_parity.py (LAYER_*_TOL for bf16, F16_* for fp16).
@@ -47,34 +52,60 @@ def _table_entries(ctx):
     return json.load(open(path))['entries']
 
 
-def force_batch32_tiles(ctx, n, h, w, batch=32):
+BENCH_TILES_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_tiles.json')
+
+
+def bench_tiles(dtype, batch, shape):
+    """tile configuration names of the conv ops of ONE benchmarked forward (dtype, batch, letterboxed shape), in op
+    order, as recorded ON THE GPU from `mdhip_get_op_info` after that forward by tools/dump_bench_tiles.py
+    (tests/golden/bench_tiles.json; 'fused' = a 1x1 that ran inside the following 3x3's launch)"""
+    key = '{}:{}x{}x{}'.format(dtype, batch, shape[0], shape[1])
+    data = json.load(open(BENCH_TILES_PATH))
+    assert key in data, 'tests/golden/bench_tiles.json has no list for {} (run tools/dump_bench_tiles.py on the GPU box)'.format(key)
+    return data[key]
+
+
+def force_table_tiles(ctx, n, h, w, batch=32, shape=(1280, 1280)):
     """
-    Forces every conv op to the configuration the shipped table holds for it at batch `batch` / 1280x1280 (matched on
-    the layer geometry N, K, taps, stride, residual; the entry whose per-image M is nearest), i.e. the kernels
-    bench.py's step launches.  Returns {op index: configuration name}.
+    Forces every conv op of a forward of `n` images of h x w to the configuration the shipped table holds for THAT layer
+    at the benchmarked launch: `batch` images of letterboxed `shape`.  The entry is matched exactly on the layer
+    geometry and the launch size -- (N, K, taps, stride, residual, M = batch x H_out x W_out at `shape`) -- and a missing
+    entry fails the test (no nearest-M substitution: since the table holds batch-32 entries at four letterbox shapes a
+    nearest match picks another layer's or another shape's tile).  Returns {op index: configuration name}.
     """
     by_name = {ctx.conv_cfg_name(c): c for c in range(ctx.num_conv_cfgs())}
-    entries = [e for e in _table_entries(ctx) if int(e.get('batch', 32)) == batch]
+    entries = {}
+    for e in _table_entries(ctx):
+        if int(e.get('batch', 32)) == batch:
+            entries[(e['n'], e['k'], e['ntaps'], e['stride'], e['has_res'], e['m'])] = e
     assert entries, 'the {} tile table has no entries measured at batch {}'.format(ctx.dtype, batch)
-    forced = {}
+    forced, missing = {}, []
     for o in ctx.op_infos():
         if o['kind'] != 0:
             continue
-        m_img = o['m'] / n
-        best = None
-        for e in entries:
-            if (e['n'], e['k'], e['ntaps'], e['stride'], e['has_res']) != (o['n'], o['k'], o['ntaps'], o['stride'], o['has_res']):
-                continue
-            cfg = by_name.get(e.get('name'), e['cfg'])
-            if not ctx.op_supports_cfg(o['op'], cfg):
-                continue
-            r = max(e['m'] / batch / m_img, m_img / (e['m'] / batch))
-            if best is None or r < best[0]:
-                best = (r, cfg)
-        if best is not None:
-            ctx.set_op_cfg(o['op'], best[1])
-            forced[o['op']] = ctx.conv_cfg_name(best[1])
+        assert (o['m'] * shape[0] * shape[1]) % (n * h * w) == 0, o
+        m_target = o['m'] * shape[0] * shape[1] // (n * h * w) * batch        # batch x H_out x W_out at `shape`
+        e = entries.get((o['n'], o['k'], o['ntaps'], o['stride'], o['has_res'], m_target))
+        if e is None:
+            missing.append((o['name'], o['n'], o['k'], m_target))
+            continue
+        cfg = by_name.get(e.get('name'), e['cfg'])
+        assert ctx.op_supports_cfg(o['op'], cfg), (o['name'], e.get('name'))
+        ctx.set_op_cfg(o['op'], cfg)
+        forced[o['op']] = ctx.conv_cfg_name(cfg)
+    assert not missing, 'no table entry for these ops at batch {} / {}x{}: {}'.format(batch, shape[0], shape[1], missing)
     return forced
+
+
+def assert_forced_equal_benchmarked(ctx, forced, dtype, batch, shape):
+    """the configurations forced from the table == the ones the benchmarked forward launched (recorded on the GPU)"""
+    convs = [o for o in ctx.op_infos() if o['kind'] == 0]
+    want = bench_tiles(dtype, batch, shape)
+    assert len(want) == len(convs), (len(want), len(convs))
+    diff = [(o['name'], forced[o['op']], w) for o, w in zip(convs, want) if w != 'fused' and forced[o['op']] != w]
+    assert not diff, 'forced tile != tile of the benchmarked step (op, forced, benchmarked): {}'.format(diff[:8])
+    fused = [o['name'] for o, w in zip(convs, want) if w == 'fused']
+    assert all('C3.m' in s and 'cv1' in s for s in fused), fused
 
 
 def _ran_tiles(ctx, forced):
@@ -128,9 +159,10 @@ def test_headline_topology_every_layer_with_the_benchmarked_tiles(dtype):
         ctx.forward(2, HH, WW)                       # the table's own choice for this batch
         own = ctx.read_predictions(2).copy()
         own_cfgs = {o['op']: o['cfg'] for o in ctx.op_infos() if o['kind'] == 0}
-        forced = force_batch32_tiles(ctx, 2, HH, WW)
+        forced = force_table_tiles(ctx, 2, HH, WW, batch=32, shape=(1280, 1280))
         n_convs = sum(1 for o in ctx.op_infos() if o['kind'] == 0)
         assert n_convs == 152 and len(forced) == n_convs, (n_convs, len(forced))
+        assert_forced_equal_benchmarked(ctx, forced, dtype, 32, (1280, 1280))
         ctx.forward(2, HH, WW)
         ran = _ran_tiles(ctx, forced)
         assert ran == forced                                         # the ops really ran the benchmarked kernels
@@ -160,38 +192,70 @@ def test_headline_topology_every_layer_with_the_benchmarked_tiles(dtype):
         ctx.close()
 
 
-def test_headline_configuration_one_full_size_image_through_the_detector():
-    """1280x1280 (the benchmarked image size), MDv5a topology, benchmarked tiles, detector seam."""
+def _one_image_through_the_detector(src_hw, net_hw, seed, box_max_tol):
+    """one image of src_hw through the detector seam (bf16 = BASELINE configs[1]) with every conv forced to the tile
+    the benchmarked batch-32 forward of letterboxed shape net_hw launches: letterboxed input bit-exact, every layer and
+    the predictions against the bf16-emulating oracle, NMS / rescale / formatting exact on the HIP predictions"""
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.detector import HIPDetector
     W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
     det = HIPDetector(W, {'batch_size': 2, 'dtype': 'bf16'})
     ctx = det._ctx
-    S = 1280
-    im = PU.structured_images(1, S, S, seed=93)[0]
-    thr = 1e-5
-    first = det.generate_detections_one_image(im, 'full.jpg', detection_threshold=thr)
-    assert 'failure' not in first
-    forced = force_batch32_tiles(ctx, 1, S, S)
-    assert len(forced) == 152
-    res = det.generate_detections_one_image(im, 'full.jpg', detection_threshold=thr)
-    assert 'failure' not in res
-    ran = _ran_tiles(ctx, forced)
-    assert ran == forced
-    pred_hip = ctx.read_predictions(1)
-    assert pred_hip.shape == (1, 102000, 8) and np.isfinite(pred_hip).all()
-    x, infos = PU.oracle_input([im], S, 64)
-    # exact: the reference's NMS / scale_coords / formatting statements applied to the HIP predictions
-    ref_same = PU.oracle_detections(torch.from_numpy(pred_hip), infos, (S, S), thr)[0]
-    assert res['detections'] == ref_same['detections']
-    assert res['max_detection_conf'] == ref_same['max_detection_conf']
-    # tolerance: the conv stack against the bf16-emulating oracle
-    pred_ref, _ = PU.oracle_forward(W, x, emulate_bf16=True)
-    e_box = PU.rel_err(pred_hip[..., :4], pred_ref[..., :4].numpy())
-    e_conf = float(np.abs(pred_hip[..., 4:] - pred_ref[..., 4:].numpy()).max())
-    print('1280x1280: box {:.2e}/{:.2e}, conf {:.2e}, {} detections'.format(e_box[0], e_box[1], e_conf, len(res['detections'])))
-    # measured: box 3.1e-2 / 3.9e-4, conf 6.2e-2 (bf16, Detect gain 22, 102000 anchors): E2E_CONF_TOL_FP32_ORACLE's regime
-    assert e_box[0] < 5e-2 and e_box[1] < LAYER_MEAN_TOL and e_conf < 8e-2
+    try:
+        im = PU.structured_images(1, src_hw[0], src_hw[1], seed=seed)[0]
+        thr = 1e-5
+        first = det.generate_detections_one_image(im, 'full.jpg', detection_threshold=thr)
+        assert 'failure' not in first
+        hh, ww = net_hw
+        assert ctx.last_num_anchors() == ctx.num_anchors(hh, ww)                  # letterboxed to net_hw
+        forced = force_table_tiles(ctx, 1, hh, ww, batch=32, shape=net_hw)
+        assert len(forced) == 152
+        assert_forced_equal_benchmarked(ctx, forced, 'bf16', 32, net_hw)
+        res = det.generate_detections_one_image(im, 'full.jpg', detection_threshold=thr)
+        assert 'failure' not in res
+        ran = _ran_tiles(ctx, forced)
+        assert ran == forced
+        x, infos = PU.oracle_input([im], 1280, 64)
+        assert tuple(x.shape[2:]) == (hh, ww)
+        np.testing.assert_array_equal(ctx.read_input(1, hh, ww), PU.bf16_round_np(x.numpy()))     # letterbox: bit-exact
+        pred_hip = ctx.read_predictions(1)
+        assert pred_hip.shape == (1, ctx.num_anchors(hh, ww), 8) and np.isfinite(pred_hip).all()
+        # exact: the reference's NMS / scale_coords / formatting statements applied to the HIP predictions
+        ref_same = PU.oracle_detections(torch.from_numpy(pred_hip), infos, (hh, ww), thr)[0]
+        assert res['detections'] == ref_same['detections']
+        assert res['max_detection_conf'] == ref_same['max_detection_conf']
+        # tolerance: every layer and the predictions against the bf16-emulating oracle
+        keep = {}
+        pred_ref, _ = PU.oracle_forward(W, x, emulate_bf16=True, keep=keep)
+        rows = []
+        for i in sorted(keep):
+            emax, emean = PU.rel_err(ctx.read_layer(i, 1), keep[i].numpy())
+            rows.append((i, emax, emean))
+        bad = [t for t in rows if t[1] > LAYER_MAX_TOL or t[2] > LAYER_MEAN_TOL]
+        assert len(rows) >= 30 and not bad, 'layers out of tolerance (layer, max, mean): {}'.format(bad)
+        e_box = PU.rel_err(pred_hip[..., :4], pred_ref[..., :4].numpy())
+        e_conf = float(np.abs(pred_hip[..., 4:] - pred_ref[..., 4:].numpy()).max())
+        print('{}x{} -> {}x{}: {} layers, worst max {:.2e} mean {:.2e}; predictions: box {:.2e}/{:.2e}, conf {:.2e}, {} detections'.format(
+            src_hw[0], src_hw[1], hh, ww, len(rows), max(t[1] for t in rows), max(t[2] for t in rows), e_box[0], e_box[1],
+            e_conf, len(res['detections'])))
+        # measured at 1280x1280: box 3.1e-2 / 3.9e-4, conf 6.2e-2 (bf16, Detect gain 22, 102000 anchors): E2E_CONF_TOL_FP32_ORACLE's regime
+        assert e_box[0] < box_max_tol and e_box[1] < LAYER_MEAN_TOL and e_conf < 8e-2
+    finally:
+        ctx.close()
+
+
+def test_headline_configuration_one_full_size_image_through_the_detector():
+    """1280x1280 (the benchmarked image size), MDv5a topology, the benchmarked tiles (exact table entries of batch 32 at
+    1280x1280, equal to the list recorded from the bench step), detector seam: every layer against the oracle."""
+    _one_image_through_the_detector((1280, 1280), (1280, 1280), seed=93, box_max_tol=5e-2)
+
+
+@pytest.mark.parametrize('src_hw,net_hw', [((1080, 1920), (768, 1280)), ((1536, 2048), (960, 1280))])
+def test_real_letterbox_shapes_through_the_detector_against_the_oracle(src_hw, net_hw):
+    """the shapes real folders produce (reference pytorch_detector.py:1226-1233: one forward per processed shape):
+    1080p video frames -> 768x1280 (BASELINE configs[3]) and 4:3 camera-trap images -> 960x1280, each
+    with the tiles its batch-32 bench line launches (tile tables are per shape since 0e1a96e)."""
+    _one_image_through_the_detector(src_hw, net_hw, seed=95 + src_hw[0] % 7, box_max_tol=5e-2)
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])

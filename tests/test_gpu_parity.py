@@ -860,3 +860,37 @@ def test_two_contexts_interleaved_and_recreated(n6):
         np.testing.assert_array_equal(again.read_predictions(2), base)
     finally:
         again.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_results_do_not_depend_on_unwritten_memory(dtype, monkeypatch):
+    """ADVICE r3 (conv_v2 pointwise loader): K-slab tails of 80- / 160- / 480-channel tensors, pad channels and halo reads
+    must never see memory nobody wrote.  MDHIP_ARENA_POISON=1 fills the arena with 0xFF bytes (NaN in every storage type)
+    at mdhip_create; the x6 topology (channel tails 80 = 64 + 16, 160 = 128 + 32, 480 = 448 + 32), plain and
+    augmented, must give finite predictions, bit-identical to a context whose arena started as zeros."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    n, hh, ww = 2, 256, 384
+    imgs = PU.structured_images(n, hh, ww, seed=5)
+    geoms = [(hh, ww, hh, ww, 0, 0)] * n
+    out = {}
+    for poison in ('0', '1'):
+        monkeypatch.setenv('MDHIP_ARENA_POISON', poison)
+        ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+        try:
+            ctx.preprocess(imgs, geoms, hh, ww)
+            ctx.forward(n, hh, ww)
+            plain = ctx.read_predictions(n).copy()
+            ctx.forward_tta(n, hh, ww)
+            tta = ctx.read_predictions(n).copy()
+            ctx.preprocess(imgs[:1], geoms[:1], hh, ww)          # a smaller batch in the same arena: the rest stays poisoned
+            ctx.forward(1, hh, ww)
+            one = ctx.read_predictions(1).copy()
+        finally:
+            ctx.close()
+        assert np.isfinite(plain).all() and np.isfinite(tta).all() and np.isfinite(one).all(), 'NaN: a kernel read unwritten memory'
+        out[poison] = (plain, tta, one)
+    for a, b in zip(out['0'], out['1']):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out['1'][2][0], out['1'][0][0])

@@ -11,8 +11,9 @@ image on both sides, at the reference's bars (md_tests.py:96-100: conf 0.005, co
 
   fp16 (the detector's default)   |d conf| <= 0.005 over ALL anchors, formatted detections within (0.005, 0.002)
   bf16 (BASELINE.json configs[1]) |d conf| <= 0.005 over ALL anchors, formatted detections within (0.005, 0.004)
-  fp8  (BASELINE.json configs[4]) with scales calibrated on OTHER images and saved: |d conf| <= 0.01, formatted
-                                  detections within (0.01, 0.008)
+  fp8  (BASELINE.json configs[4]) with scales calibrated on OTHER images and saved: |d conf| <= 0.006 (measured
+                                  0.0048-0.0053: ON the reference's 0.005 bar, not inside it), formatted detections
+                                  within (0.01, 0.008)
 The originals are 2560 pixels wide, like camera-trap images (the device letterboxes them to 640): the reference rounds
 every box to integer pixels of the ORIGINAL (pytorch_detector.py:1379), so a sub-pixel difference can flip a rounded
 corner by 1 / 2560 = 0.0004 and a width or height by two of them; the coordinate bars are the reference's 0.001 plus
@@ -33,7 +34,7 @@ ORIG = 2560                   # camera-trap sized originals, letterboxed to SIZE
 BARS = {                      # dtype: (max |d conf| over all anchors, detection conf bar, detection coord bar)
     'fp16': (0.005, 0.005, 0.002),
     'bf16': (0.005, 0.005, 0.004),
-    'fp8': (0.01, 0.01, 0.008),
+    'fp8': (0.006, 0.01, 0.008),       # measured 0.0048-0.0053: fp8 sits ON the reference's 0.005, it does not clear it (README)
 }
 
 

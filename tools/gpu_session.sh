@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 GPU-box visits (stages picked on the command line); everything that should come back goes under gpurun_out/.
+# One GPU-box visit (stages picked on the command line; any other argument is a command line run verbatim); everything that should come back goes under gpurun_out/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
@@ -23,7 +23,7 @@ case "$STAGE" in
     timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --profile-out gpurun_out/ops_b32.json > gpurun_out/bench.log 2>&1
     echo "bench exit $?" >> gpurun_out/bench.log ;;
   prof)
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r2 -- \
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o run -- \
        python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --lean > "$OLDPWD/gpurun_out/rocprof.log" 2>&1)
     find gpurun_out/prof -name "*stats*" | head >> gpurun_out/rocprof.log
     find gpurun_out/prof -type f ! -name "*stats*" -size +2M -delete 2>/dev/null ;;
