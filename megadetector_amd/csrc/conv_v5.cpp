@@ -57,9 +57,8 @@ __device__ __forceinline__ float silu_f32(float x) {
 typedef mdhip_f32x2 f32x2;
 
 constexpr int v5_run_pieces(int bm) { return (bm + 2 + 7) / 8; }
-// the row of zeros (256 bytes), behind it the staged bias of the workgroup's BN channels, behind that 256 bytes nobody reads
-// (the landing area of the residual touches, see res_touch): whole KiB
-constexpr int v5_zero_bytes(int bn) { return (256 + bn * 4 + 256 + 1023) / 1024 * 1024; }
+// the row of zeros (256 bytes) and, behind it, the staged bias of the workgroup's BN channels: whole KiB
+constexpr int v5_zero_bytes(int bn) { return (256 + bn * 4 + 1023) / 1024 * 1024; }
 // 2 run buffers + 2 weight stages + the zero row / bias area
 constexpr int v5_lds_bytes(int bm, int bn) { return 2 * v5_run_pieces(bm) * 1024 + 2 * bn * 128 + v5_zero_bytes(bn); }
 constexpr int v5_blocks_per_cu(int bm, int bn, int nw) {
@@ -121,8 +120,7 @@ conv_v5_kernel(const ConvArgs p) {
     // the row of zeros that invalid (pixel, tap) pairs read; behind it (offset 256 of the same KiB) the bias of this
     // workgroup's BN output channels, staged once: the epilogue of every tile reads its 4 channels per fragment column
     // with one ds_read_b128 instead of a scalar load + wait per column (5 dependent round trips per tile)
-    static_assert(BN * 4 + 512 <= v5_zero_bytes(BN), "bias staging area + dump area");
-    constexpr int DUMP_OFF = ZERO_OFF + 256 + BN * 4;
+    static_assert(BN * 4 + 256 <= v5_zero_bytes(BN), "bias staging area");
     if (tid < 16) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
     for (int c = tid; c < BN; c += NW * 64)
         *(__attribute__((address_space(3))) float*)(smem + ZERO_OFF + 256 + c * 4) = (n0 + c < p.n_rows) ? p.bias[n0 + c] : 0.f;
@@ -459,30 +457,6 @@ conv_v5_kernel(const ConvArgs p) {
         }
     };
 
-    // ---- residual touch (8-wave tiles) ------------------------------------------------------------------
-    // The residual of a bottleneck is the tensor its output overwrites: written two launches earlier, 131 .. 262 MB, i.e.
-    // an L2 miss for every line -- and in the lock-step 8-wave tile all waves of the CU sit in their epilogues together,
-    // so each pixel row used to wait out most of an HBM round trip (stamps: epilogue 902 against 434 cycles per step
-    // with / without residual on the L6 shape).  A few steps before the tile's last one every wave therefore touches the
-    // lines of its TM x TN residual block: one dword per line, as an LDS-DMA load into 256 bytes of LDS nobody reads -- no
-    // destination register to keep alive, completion is covered by the step's own vmcnt(0).  The epilogue's loads then
-    // hit L2.  Three instructions per wave and tile (first and last dword of every pixel's TN-channel segment).
-    auto res_touch = [&](int tile_m, int t) __attribute__((always_inline)) {
-        int l = lane;
-        asm volatile("" : "+v"(l));
-        const int idx = t * 64 + l;
-        const int px = idx >> 1;
-        const long long rows_left = (long long)p.M - (long long)tile_m * BM;
-        const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(p.res + (size_t)tile_m * BM * p.ld_res), 0, (int)min(rows_left * p.ld_res * 2, 0x7fffffffLL), 0x00020000);
-        const unsigned off = (unsigned)(wm * TM + px) * (unsigned)p.ld_res * 2u + (unsigned)(n0 + wn * TN) * 2u +
-                             ((idx & 1) ? (unsigned)(TN * 2 - 4) : 0u);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, smem + DUMP_OFF, 4, px < TM ? off : kOOB, 0, 0, 0);
-    };
-    constexpr int TOUCHES = (2 * TM + 63) / 64;
-    // (developer knob, tools/convbench.cpp MDHIP_DEV_PARAM: 0 = default lead, 1 = no touch, 2 .. = other leads)
-    const int touch_lead = !p.res || !LEAN || p.dev_param == 1 ? -1 : (p.dev_param >= 2 ? p.dev_param - 2 : 3);
-
     // ---- prologue: run (first tile, group 0, r 0) in buffer 0, weight slabs of steps 0 and 1 ----------
     run_setup();
 #pragma unroll
@@ -572,14 +546,6 @@ conv_v5_kernel(const ConvArgs p) {
             if (after_epilogue) stamp(4); else stamp(2);
             after_epilogue = false;
             MDHIP_FENCE();
-            if constexpr (LEAN) {
-                // steps left in this tile after this one: (runs left) * 3 + (2 - s)
-                if (touch_lead >= 0 && ((G - 1 - c_cg) * 3 + (2 - c_r)) * 3 + (2 - s) == touch_lead) {
-#pragma unroll
-                    for (int t = 0; t < TOUCHES; ++t) res_touch(c_tile, t);
-                }
-                MDHIP_FENCE();
-            }
 
             // ---- second half: the k 0..31 fragments of the next step, MFMAs on k 32..63, and the DMA
             //      pieces (weight slab of step+2; in steps 0 and 1 the next run) behind the MFMA chunks ----

@@ -1112,8 +1112,8 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     ctx->pred_offs[0] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * ctx->no * 4);
     ctx->pred_offs[1] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * ctx->no * 4);
     ctx->pred_off = ctx->pred_offs[0];
-    size_t nms_kv[4];
-    for (int i = 0; i < 4; ++i) nms_kv[i] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * 4);
+    size_t nms_kv[6];
+    for (int i = 0; i < 6; ++i) nms_kv[i] = P.alloc_bytes((size_t)max_batch * ctx->a_cap * 4);
     const size_t nms_seg = P.alloc_bytes((size_t)max_batch * kNmsScanParts * 4);
     ctx->nms_out_off = P.alloc_bytes((size_t)max_batch * kNmsMaxDet * 6 * 4);
     ctx->nms_cnt_off = P.alloc_bytes((size_t)max_batch * 4);
@@ -1189,10 +1189,10 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
             CREATE_TRY(hipMemset(ctx->warena + ctx->packed[i].scale_off, 0, (size_t)ctx->packed[i].n_rows * 4));
         }
     }
-    ctx->nms_scr.keys[0] = (uint32_t*)(ctx->arena + nms_kv[0]);
-    ctx->nms_scr.keys[1] = (uint32_t*)(ctx->arena + nms_kv[1]);
-    ctx->nms_scr.vals[0] = (uint32_t*)(ctx->arena + nms_kv[2]);
-    ctx->nms_scr.vals[1] = (uint32_t*)(ctx->arena + nms_kv[3]);
+    for (int i = 0; i < 3; ++i) {
+        ctx->nms_scr.keys[i] = (uint32_t*)(ctx->arena + nms_kv[i]);
+        ctx->nms_scr.vals[i] = (uint32_t*)(ctx->arena + nms_kv[3 + i]);
+    }
     ctx->nms_scr.cap = ctx->a_cap;
     ctx->nms_scr.seg_cnt = (uint32_t*)(ctx->arena + nms_seg);
     CREATE_TRY(hipDeviceSynchronize());

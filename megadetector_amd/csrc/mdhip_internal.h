@@ -331,8 +331,8 @@ hipError_t launch_s2d_to_nchw_f32(const uint16_t* in, float* out, int n, int h, 
 // ---------------------------------------------------------------------------------------
 constexpr int kNmsScanParts = 16;   // workgroups per image of the candidate scan (nms_kernels.cpp stage A)
 struct NmsScratch {
-    uint32_t* keys[2];     // [n][cap] each
-    uint32_t* vals[2];
+    uint32_t* keys[3];     // [n][cap] each: 0 / 2 = the band being sorted (ping-pong), 1 = every candidate in anchor order
+    uint32_t* vals[3];
     int cap;               // candidates capacity per image (= max anchors)
     uint32_t* seg_cnt;     // [n][kNmsScanParts] candidates found by each scan workgroup
 };
