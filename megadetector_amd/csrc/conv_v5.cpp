@@ -344,7 +344,7 @@ conv_v5_kernel(const ConvArgs p) {
         // residual rows in flight ahead of the row being finished: 1 (two workgroups per CU: the partner workgroup's
         // MFMAs cover the round trip) or 2 (LEAN = one 8-wave workgroup per CU: every wave of the CU is in its epilogue
         // at the same time, and each pixel row would otherwise wait out most of an HBM round trip on its own)
-        constexpr int RA = LEAN ? 2 : 1, RS = RA + 1;
+        constexpr int RA = LEAN ? ((PROF & 32) ? 4 : 2) : 1, RS = RA + 1;     // (PROF 32: developer variant, all rows up front)
         uint4 rpair[RS][NPAIR > 0 ? NPAIR : 1];
         uint2 rlast[RS];
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -622,7 +622,8 @@ conv_v5_kernel(const ConvArgs p) {
     X(13, 320, 160, 4, 2, 6) \
     X(14, 320, 160, 4, 2, 22) \
     X(15, 320, 160, 4, 2, 2) \
-    X(16, 320, 160, 4, 2, 3)
+    X(16, 320, 160, 4, 2, 3) \
+    X(17, 320, 160, 4, 2, 32)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
@@ -631,7 +632,7 @@ static const ConvCfg g_cfgs5[] = {
     MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
 #undef X
 };
-constexpr int kNumProf5 = 9;
+constexpr int kNumProf5 = 10;
 
 // ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp and the C = 80
 // strip kernel of conv_v5c.cpp (same K order, same results), then the developer variants
