@@ -470,301 +470,14 @@ conv_c80f_kernel(const ConvArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// The fused bottleneck again, with TWO channel fragments per wave (round 4).
-//
-// conv_c80f_kernel above is bound by LDS reads: its ten waves own one 16-channel fragment each, so every activation
-// fragment is read by five waves -- one ds_read_b128 (1 KiB) per MFMA, 1.5 MB per 160-pixel tile against 128 bytes per
-// clock (PMC round 3: 1.13 LDS instructions per MFMA, 58 % of the wave cycles waiting, MFMA pipe 0.22).  Here the first
-// four waves own a PAIR of channel fragments and use every activation fragment for two MFMAs:
-//   waves 0 .. 3: pixel half wm = w & 1 (FM fragments), channels 32 * (w >> 1) .. + 31 (two fragments, 144 weight registers)
-//   waves 4 .. 7: channels 64 .. 79 (one fragment), a quarter of the tile's pixel fragments each (3 / 3 / 2 / 2 of ten)
-// Eight waves, one of each kind per SIMD: 13 / 13 / 12 / 12 MFMAs per half step and SIMD (ten waves: 15 / 15 / 10 / 10),
-// and the tile's fragment reads drop from 50 to 30 per half step, the conversion's from 5 to 3 per pixel fragment and
-// k-step.  Same strip walk, ring, conversion, K order and MFMA chain per accumulator: bit-identical.
+// (Round 4, built, measured, removed -- commit history has it: the fused bottleneck with TWO channel fragments per wave
+// (four waves with 144 weight registers and 5 x 2 accumulator fragments + four one-fragment quarter waves: 30 instead
+// of 50 fragment reads per half step, 13 / 13 / 12 / 12 MFMAs per SIMD).  Bit-identical, and 11 % SLOWER (0.83 against
+// 0.745 ms per bottleneck, profiles/r4_c80g_two_fragments.txt): with the weights of two fragments resident a wave has no
+// register left to read the next half step's activation fragments ahead, so every half step exposes its LDS round
+// trip, and two such waves per SIMD hide less of it than the three light ones above.  The kernel is bound by LDS
+// latency at its occupancy, not by LDS bandwidth.)
 // ---------------------------------------------------------------------------------------
-template <int BM>
-__global__ void __launch_bounds__(8 * 64, 1)
-conv_c80g_kernel(const ConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int kNWc = 8, NTH = kNWc * 64;
-    constexpr int MF = BM / 16;                                // pixel fragments of a tile
-    constexpr int FM2 = MF / 2;                                // ... of a two-fragment wave (a pixel half)
-    constexpr int Q0 = (MF + 3) / 4, Q1 = (MF + 2) / 4, Q2 = (MF + 1) / 4, Q3 = MF / 4;    // ... of the one-fragment waves
-    static_assert(MF % 2 == 0 && Q0 + Q1 + Q2 + Q3 == MF && Q0 <= 3 && Q3 >= 1, "tile split");
-    constexpr int RUNB = c80_run_bytes(BM), PIECES = RUNB / 1024, NP = (PIECES + kNWc - 1) / kNWc;
-    constexpr int STAGE_OFF = 3 * RUNB;
-    constexpr int W1_OFF = 4 * RUNB, ZERO_OFF = W1_OFF + kW1Bytes, BIAS_OFF = ZERO_OFF + c80_zero_bytes(FM2);
-    constexpr int SCRATCH_OFF = BIAS_OFF + 320;
-    constexpr int WPRE_OFF = SCRATCH_OFF + 1024;
-    constexpr int BPRE_OFF = WPRE_OFF + 80 * 192;
-    constexpr int TF = (BM + 2 + 15) / 16;                     // fragments of a T row (BM + 2 pixels)
-    constexpr int TF2 = (TF + 1) / 2;                          // ... per two-fragment wave
-    constexpr int TQ = (TF + 3) / 4;                           // ... per one-fragment wave
-    static_assert(((TF2 - 1) * 16 + 15) * kPixB + 16 <= c80_zero_bytes(FM2) + 0, "zero region covers the conversion's immediates");
-
-    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
-    lds_char* const smem = (lds_char*)smem_generic;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool two = wave < 4;                                  // wave-uniform: this wave owns two channel fragments
-    const int nf0 = two ? 2 * (wave >> 1) : 4;                  // its first (or only) 16-channel fragment
-    const int q = wave & 3;
-    // first pixel fragment of the wave inside the tile, and of its share of a T row
-    const int mf0 = two ? (wave & 1) * FM2 : (q == 0 ? 0 : q == 1 ? Q0 : q == 2 ? Q0 + Q1 : Q0 + Q1 + Q2);
-    const int tf0 = two ? (wave & 1) * TF2 : q * TQ;
-    const int tfn = two ? min(TF2, TF - tf0) : max(0, min(TQ, TF - tf0));
-    const int m15 = lane & 15, kb = lane >> 4;
-
-    const int strips = p.tiles_n, segs = p.tiles_per_xcd, seg_rows = p.m_streams, total = p.tiles_m;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const int per_xcd = (total + 7) / 8;
-    const int u_lo = xcd * per_xcd, u_hi = min(u_lo + per_xcd, total);
-    if (u_lo + slot >= u_hi) return;
-
-    for (int c = tid * 16; c < c80_zero_bytes(FM2); c += NTH * 16)
-        *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + c) = make_uint4(0, 0, 0, 0);
-    for (int c = tid; c < 9 * 80 * 2; c += NTH) {
-        const int t = c / 160, rem = c - t * 160, ch = rem >> 1, half = rem & 1;
-        *(__attribute__((address_space(3))) uint4*)(smem + W1_OFF + c * 16) =
-            *(const uint4*)(p.wgt4 + (size_t)ch * p.k_pad4 + (9 + t) * 64 + half * 8);
-    }
-    // the 64-channel group's weight fragments of this wave's channel fragment(s): (tap, k-half) -> row nf*16 + m15
-    frag8_t wreg[2][9][2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                wreg[f][t][kk] = *(const frag8_t*)(p.wgt4 + (size_t)((nf0 + (two ? f : 0)) * 16 + m15) * p.k_pad4 + t * 64 + kk * 32 + kb * 8);
-    for (int c = tid; c < 80 * 12; c += NTH) {
-        const int ch = c / 12, qq = c - ch * 12;
-        *(__attribute__((address_space(3))) uint4*)(smem + WPRE_OFF + c * 16) = *(const uint4*)(p.wgt_pre + (size_t)ch * p.k_pad_pre + qq * 8);
-    }
-    for (int c = tid; c < 80; c += NTH) {
-        *(__attribute__((address_space(3))) float*)(smem + BPRE_OFF + c * 4) = p.bias_pre[c];
-        *(__attribute__((address_space(3))) float*)(smem + BIAS_OFF + c * 4) = p.bias[c];       // (registers go to the weights)
-    }
-
-    __amdgpu_buffer_rsrc_t in_rsrc, res_rsrc, out_rsrc;
-    const int img_in_bytes = p.HoWo * p.ld_in * 2, img_out_bytes = p.HoWo * p.ld_out * 2, img_res_bytes = p.HoWo * p.ld_res * 2;
-    int x0 = 0;
-    // x row iy of the current strip into the staging slot (out-of-image rows and pixels: zeros, never used)
-    auto issue_row = [&](int iy) __attribute__((always_inline)) {
-        const bool row_ok = (unsigned)iy < (unsigned)p.H;
-        const unsigned row_term = (unsigned)((iy * p.W + x0 - 1) * p.ld_in * 2);
-        // (piece -> pixel, chunk worked out here from an opaque copy of the lane id: a few divisions per tile instead of
-        // registers of hoisted offsets for the whole kernel)
-        int le = lane;
-        asm volatile("" : "+v"(le));
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int pc = wave + kNWc * k;
-            const int g = pc * 64 + le;
-            const int px = g / 10, c16 = g - px * 10;
-            const bool ok = row_ok && pc < PIECES && px < BM + 2 && (unsigned)(x0 - 1 + px) < (unsigned)p.W;
-            MDHIP_DMA16(in_rsrc, smem + (pc < PIECES ? STAGE_OFF + pc * 1024 : SCRATCH_OFF),
-                        ok ? row_term + (unsigned)((px * p.ld_in + c16 * 8) * 2) : kOOB, 0);
-        }
-    };
-
-    const unsigned lane_a = (unsigned)((mf0 * 16 + m15) * kPixB + kb * 16);
-    const unsigned lane_a1 = kb < 2 ? lane_a + 128u : 0xffffffffu;
-    const unsigned lane_z = (unsigned)(ZERO_OFF + m15 * kPixB + (kb & 1) * 16);
-    // 16-channel group: the lanes holding k 16 .. 31 read zeros on the ACTIVATION side (lane_z), so their weight operand may
-    // be any finite value -- they read the weights of k 0 .. 15 again, which keeps (fragment, tap) at immediate offsets
-    // for every lane (a per-lane step cost nine address registers)
-    const unsigned lane_w1 = (unsigned)(W1_OFF + (nf0 * 16 + m15) * 32 + (kb & 1) * 16);
-    constexpr unsigned lane_w1_f = 16u * 32u;                                    // the wave's second fragment: 16 rows on
-    constexpr unsigned lane_w1_step = 80u * 32u;
-
-    // T row iy = SiLU(W1 x + b1) of the staged x row into ring slot `ts` (zero outside the image): this wave's `tfn` pixel
-    // fragments from tf0 on, for its FNW channel fragments
-    auto convert = [&](int iy, int ts, auto fnw_t, auto tfw_t) __attribute__((always_inline)) {
-        constexpr int FNW = decltype(fnw_t)::value, TFW = decltype(tfw_t)::value;
-        const bool row_ok = (unsigned)iy < (unsigned)p.H;
-        // (addresses from an opaque copy of the lane id: computed here, not kept in registers across the 3x3's main loop)
-        int le = lane;
-        asm volatile("" : "+v"(le));
-        const int m15 = le & 15, kb = le >> 4;
-        const unsigned lane_wp = (unsigned)(WPRE_OFF + (nf0 * 16 + m15) * 192 + kb * 16);
-        const unsigned lane_x = (unsigned)(STAGE_OFF + (tf0 * 16 + m15) * kPixB + kb * 16);
-        const unsigned lane_x2 = kb < 2 ? lane_x + 128u : (unsigned)(ZERO_OFF + m15 * kPixB + (kb & 1) * 16);
-        const unsigned lane_t = (unsigned)((tf0 * 16 + m15) * kPixB + (nf0 * 16 + kb * 4) * 2);
-        frag8_t wp[FNW][3];
-        f32x4 bpre4[FNW];
-#pragma unroll
-        for (int f = 0; f < FNW; ++f) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                wp[f][t] = *(const __attribute__((address_space(3))) frag8_t*)(smem + lane_wp + f * 16 * 192 + t * 64);
-            bpre4[f] = *(const __attribute__((address_space(3))) f32x4*)(smem + BPRE_OFF + ((nf0 + f) * 16 + kb * 4) * 4);
-        }
-#pragma unroll
-        for (int fr = 0; fr < TFW; ++fr) {
-            if (fr < tfn) {                                                           // wave-uniform
-                f32x4 c[FNW];
-#pragma unroll
-                for (int f = 0; f < FNW; ++f) c[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const frag8_t xf = *(const __attribute__((address_space(3))) frag8_t*)(smem + (t < 2 ? lane_x + t * 64 : lane_x2) + fr * 16 * kPixB);
-#pragma unroll
-                    for (int f = 0; f < FNW; ++f) c[f] = MDHIP_MFMA(wp[f][t], xf, c[f]);
-                }
-                const int px = (tf0 + fr) * 16 + m15;
-                const bool ok = row_ok && px < BM + 2 && (unsigned)(x0 - 1 + px) < (unsigned)p.W;
-#pragma unroll
-                for (int f = 0; f < FNW; ++f) {
-                    float v[4];
-                    mdhip_bias4(c[f], bpre4[f], v);
-                    mdhip_silu4(v);
-                    uint2 d;
-                    d.x = ok ? st_pack2(v[0], v[1]) : 0u;
-                    d.y = ok ? st_pack2(v[2], v[3]) : 0u;
-                    if (px < BM + 2)
-                        *(__attribute__((address_space(3))) uint2*)(smem + ts * RUNB + lane_t + f * 32 + fr * 16 * kPixB) = d;
-                }
-            }
-        }
-    };
-
-    // one output tile (image row y of the strip): 27 half steps and the epilogue for this wave's FMW pixel fragments
-    // (from mf0 on) x FNW channel fragments
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    auto tile = [&](int y, int s0, auto fnw_t, auto fmw_t) __attribute__((always_inline)) {
-        constexpr int FNW = decltype(fnw_t)::value, FMW = decltype(fmw_t)::value;
-        // (zeroed here, not at the end of the previous tile: registers of zeros would stay live across the conversion)
-        f32x4 acc[FNW][FMW];
-#pragma unroll
-        for (int f = 0; f < FNW; ++f)
-#pragma unroll
-            for (int i = 0; i < FMW; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x2 rres[FNW][FMW];
-        auto load_res = [&](int f) __attribute__((always_inline)) {
-            int le = lane;
-            asm volatile("" : "+v"(le));
-            const int xr = x0 + mf0 * 16 + (le & 15);
-#pragma unroll
-            for (int i = 0; i < FMW; ++i) {
-                const int x = xr + i * 16;
-                const unsigned off = x < p.W ? (unsigned)(((y * p.W + x) * p.ld_res + (nf0 + f) * 16 + (le >> 4) * 4) * 2) : kOOB;
-                rres[f][i] = __builtin_amdgcn_raw_buffer_load_b64(res_rsrc, off, 0, 0);
-            }
-        };
-        unsigned rb[3], rb1[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            int sl = s0 + r;
-            sl = sl >= 3 ? sl - 3 : sl;
-            rb[r] = (unsigned)(sl * RUNB) + lane_a;
-            rb1[r] = kb < 2 ? (unsigned)(sl * RUNB) + lane_a1 : lane_z;
-        }
-#pragma unroll
-        for (int hs = 0; hs < 27; ++hs) {
-            frag8_t xa[FMW], w[FNW];
-            if (hs < 18) {
-                const int t = hs >> 1, kk = hs & 1, r = t / 3, s = t - 3 * r;
-#pragma unroll
-                for (int i = 0; i < FMW; ++i)
-                    xa[i] = *(const __attribute__((address_space(3))) frag8_t*)(smem + rb[r] + (i * 16 + s) * kPixB + kk * 64);
-#pragma unroll
-                for (int f = 0; f < FNW; ++f) w[f] = wreg[f][t][kk];
-            } else {
-                // the residual of this tile's first channel fragment (x at this row: an L2 hit, the strip's DMA read it two
-                // tiles ago), requested nine half steps ahead of the epilogue -- not at the tile's start: registers the
-                // main loop needs; the second fragment's follows at the start of the epilogue, under the first one's SiLUs
-                if (hs == 18 && p.res) load_res(0);
-                const int t = hs - 18, r = t / 3, s = t - 3 * r;
-#pragma unroll
-                for (int i = 0; i < FMW; ++i)
-                    xa[i] = *(const __attribute__((address_space(3))) frag8_t*)(smem + rb1[r] + (i * 16 + s) * kPixB);
-#pragma unroll
-                for (int f = 0; f < FNW; ++f)
-                    w[f] = *(const __attribute__((address_space(3))) frag8_t*)(smem + lane_w1 + f * lane_w1_f + t * lane_w1_step);
-            }
-#pragma unroll
-            for (int f = 0; f < FNW; ++f)
-#pragma unroll
-                for (int i = 0; i < FMW; ++i) acc[f][i] = MDHIP_MFMA(w[f], xa[i], acc[f][i]);
-        }
-        const int xw = x0 + mf0 * 16 + m15;
-#pragma unroll
-        for (int f = 0; f < FNW; ++f) {
-            if (f + 1 < FNW && p.res) load_res(f + 1);
-#pragma unroll
-            for (int i = 0; i < FMW; ++i) {
-                float v[4];
-                const f32x4 b4 = *(const __attribute__((address_space(3))) f32x4*)(smem + BIAS_OFF + ((nf0 + f) * 16 + kb * 4) * 4);
-                mdhip_bias4(acc[f][i], b4, v);
-                if (p.act) mdhip_silu4(v);
-                if (p.res) {
-                    v[0] += st_unpack((uint16_t)(rres[f][i][0] & 0xffff));
-                    v[1] += st_unpack((uint16_t)(rres[f][i][0] >> 16));
-                    v[2] += st_unpack((uint16_t)(rres[f][i][1] & 0xffff));
-                    v[3] += st_unpack((uint16_t)(rres[f][i][1] >> 16));
-                }
-                const u32x2 d = {st_pack2(v[0], v[1]), st_pack2(v[2], v[3])};
-                const int x = xw + i * 16;
-                const unsigned off = x < p.W ? (unsigned)(((y * p.W + x) * p.ld_out + (nf0 + f) * 16 + kb * 4) * 2) : kOOB;
-                __builtin_amdgcn_raw_buffer_store_b64(d, out_rsrc, off, 0, 0);
-            }
-        }
-    };
-    typedef std::integral_constant<int, 1> one_t;
-    typedef std::integral_constant<int, 2> two_t;
-    // wave-uniform dispatch on the wave's kind (the stores of a tile: 2 * FM2, Q0 or Q3 per wave)
-    auto do_convert = [&](int iy, int ts) __attribute__((always_inline)) {
-        if (two) convert(iy, ts, two_t{}, std::integral_constant<int, TF2>{});
-        else convert(iy, ts, one_t{}, std::integral_constant<int, TQ>{});
-    };
-    const bool big_q = !two && (q == 0 ? Q0 : q == 1 ? Q1 : q == 2 ? Q2 : Q3) == Q0;
-
-    bool first = true;
-    for (int u = u_lo + slot; u < u_hi; u += slots) {
-        const int xs = u % strips;
-        const int t2 = u / strips;
-        const int sg = t2 % segs, b = t2 / segs;
-        x0 = xs * BM;
-        const int y_lo = sg * seg_rows, y_hi = min(y_lo + seg_rows, p.H);
-        in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * p.HoWo * p.ld_in), 0, img_in_bytes, 0x00020000);
-        out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.out + (size_t)b * img_out_bytes), 0, img_out_bytes, 0x00020000);
-        if (p.res)
-            res_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (size_t)b * p.HoWo * p.ld_res), 0, img_res_bytes, 0x00020000);
-        for (int k = 0; k < 3; ++k) {
-            if (!first || k > 0) __builtin_amdgcn_s_barrier();               // staging slot and ring slot k are free
-            first = false;
-            issue_row(y_lo - 1 + k);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            do_convert(y_lo - 1 + k, k);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                           // the three T rows are complete
-        if (y_lo + 1 < y_hi) issue_row(y_lo + 2);
-        int s0 = 0;                                                             // ring slot of T row y - 1
-        for (int y = y_lo; y < y_hi; ++y) {
-            if (two) tile(y, s0, two_t{}, std::integral_constant<int, FM2>{});
-            else if (big_q) tile(y, s0, one_t{}, std::integral_constant<int, Q0>{});
-            else tile(y, s0, one_t{}, std::integral_constant<int, Q3>{});
-            if (y + 1 < y_hi) {
-                // x row y + 2 is staged (older than this tile's stores); every wave is past its reads of T row y - 1
-                if (two) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * FM2) : "memory");
-                else if (big_q) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Q0) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Q3) : "memory");
-                __builtin_amdgcn_s_barrier();
-                do_convert(y + 2, s0);                                           // T row y + 2 takes the slot of row y - 1
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (y + 2 < y_hi) issue_row(y + 3);                              // the staging slot is free again
-                s0 = s0 == 2 ? 0 : s0 + 1;
-            }
-        }
-    }
-#endif  // __HIP_DEVICE_COMPILE__
-}
-
 // ---------------------------------------------------------------------------------------
 // configuration table (ids local to this file; conv_v5.cpp appends them to its own)
 // ---------------------------------------------------------------------------------------
@@ -790,10 +503,8 @@ hipError_t conv5c_init() {
                                 (int)g_cfgs5c[id].lds_bytes);                                       \
     if (e == hipSuccess)                                                                         \
         e = hipFuncSetAttribute((const void*)conv_c80f_kernel<bm, wm>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                c80f_lds_bytes(bm, wm));                                            \
-    if (e == hipSuccess)                                                                         \
-        e = hipFuncSetAttribute((const void*)conv_c80g_kernel<bm>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 c80f_lds_bytes(bm, wm));
+
     MDHIP_CONV5C_CFGS(X)
 #undef X
     return e;
@@ -826,14 +537,10 @@ hipError_t conv5c_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     p.tiles_m = n_img * segs * strips;
     const int slots = std::max(1, std::min(32 * c.blocks_per_cu, (p.tiles_m + 7) / 8));
     const dim3 grid((unsigned)(8 * slots));
-    // the fused bottleneck runs conv_c80g_kernel (two channel fragments per wave); MDHIP_C80F_OLD=1 keeps the ten-wave
-    // conv_c80f_kernel for A/B measurements (same bits)
-    static const bool old_fused = getenv("MDHIP_C80F_OLD") && atoi(getenv("MDHIP_C80F_OLD")) != 0;
     switch (cfg) {
 #define X(id, bm, wm)                                                                             \
     case id:                                                                                      \
-        if (a.wgt_pre && !old_fused) hipLaunchKernelGGL((conv_c80g_kernel<bm>), grid, dim3(8 * 64), c80f_lds_bytes(bm, wm), s, p); \
-        else if (a.wgt_pre) hipLaunchKernelGGL((conv_c80f_kernel<bm, wm>), grid, dim3((wm) * 5 * 64), c80f_lds_bytes(bm, wm), s, p); \
+        if (a.wgt_pre) hipLaunchKernelGGL((conv_c80f_kernel<bm, wm>), grid, dim3((wm) * 5 * 64), c80f_lds_bytes(bm, wm), s, p); \
         else hipLaunchKernelGGL((conv_c80_kernel<bm, wm>), grid, dim3((wm) * 5 * 64), c.lds_bytes, s, p); \
         break;
         MDHIP_CONV5C_CFGS(X)
