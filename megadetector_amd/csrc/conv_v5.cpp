@@ -114,7 +114,9 @@ conv_v5_kernel(const ConvArgs p) {
     const int n0 = tile_n * BN;
     const int G = p.groups;                       // 64-channel groups (the last one may be half full)
     const int runs_per_tile = 3 * G;              // (channel group, kernel row) pairs
-    const int steps_per_tile = 9 * G;
+    // a last channel group of at most 32 channels with the paired packing: its runs take two steps (taps 0 + 1, tap 2)
+    const bool pair = p.wgt4p != nullptr && (p.C8 & 7) != 0 && (p.C8 & 7) <= 4;
+    const int steps_per_tile = pair ? 9 * G - 3 : 9 * G;
     const int total_runs = my_tiles * runs_per_tile;
 
     // the row of zeros that invalid (pixel, tap) pairs read; behind it (offset 256 of the same KiB) the bias of this
@@ -128,8 +130,9 @@ conv_v5_kernel(const ConvArgs p) {
     // ---- weight stream: slab (cg, tap) = 128 bytes of every row at byte offset step * 128 ---------
     const int lr = lane >> 3;
     const int jj = (lane & 7) ^ lr;
+    const int w_kpad = pair ? p.k_pad4p : p.k_pad4;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.wgt4 + (size_t)n0 * p.k_pad4), 0, kNumRecords, 0x00020000);
+        (void*)((pair ? p.wgt4p : p.wgt4) + (size_t)n0 * w_kpad), 0, kNumRecords, 0x00020000);
     // LEAN (the 8-wave tiles, which have no register to spare): one offset register for the wave's first piece, the
     // others are that + i * NW * 8 rows; needs every row of the tile to exist (conv5_supports: n_rows % BN == 0)
     constexpr bool LEAN = FM == 5 && FN == 5;
@@ -137,9 +140,9 @@ conv_v5_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < (LEAN ? 1 : B_PER); ++i) {
         const int row = (i * NW + wave) * 8 + lr;
-        b_off[i] = (LEAN || (row < BN && n0 + row < p.n_rows)) ? (unsigned)(row * p.k_pad4 + jj * 8) * 2u : kOOB;
+        b_off[i] = (LEAN || (row < BN && n0 + row < p.n_rows)) ? (unsigned)(row * w_kpad + jj * 8) * 2u : kOOB;
     }
-    const unsigned b_stride = (unsigned)(NW * 8 * p.k_pad4) * 2u;      // (LEAN) bytes between a wave's pieces
+    const unsigned b_stride = (unsigned)(NW * 8 * w_kpad) * 2u;        // (LEAN) bytes between a wave's pieces
     int l_step = 0;                                // the weight loader's step inside a tile (same for every tile)
     // LEAN: a piece is issued with as few instructions as the hardware needs -- every instruction between two MFMA chunks
     // is matrix-pipe idle time, because the two waves of a SIMD run the same code between the same barriers.  Weight
@@ -344,7 +347,7 @@ conv_v5_kernel(const ConvArgs p) {
         // residual rows in flight ahead of the row being finished: 1 (two workgroups per CU: the partner workgroup's
         // MFMAs cover the round trip) or 2 (LEAN = one 8-wave workgroup per CU: every wave of the CU is in its epilogue
         // at the same time, and each pixel row would otherwise wait out most of an HBM round trip on its own)
-        constexpr int RA = LEAN ? ((PROF & 32) ? 4 : 2) : 1, RS = RA + 1;     // (PROF 32: developer variant, all rows up front)
+        constexpr int RA = LEAN ? 2 : 1, RS = RA + 1;     // (all five rows up front, round 4: 1 - 4 % slower)
         uint4 rpair[RS][NPAIR > 0 ? NPAIR : 1];
         uint2 rlast[RS];
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -502,32 +505,47 @@ conv_v5_kernel(const ConvArgs p) {
 #define MDHIP_FENCE() __builtin_amdgcn_sched_barrier(0)
     // a half-full last channel group (C_in mod 64 <= 32) has nothing in k 32..63: its second-half MFMAs are skipped
     const bool tail_short = (p.C8 & 7) != 0 && (p.C8 & 7) <= 4;
-    constexpr int DMA_MAX = B_PER + A_H0, DMA_PER_G = (DMA_MAX + FN - 1) / FN;
+    // DMA slots behind the MFMA chunks of a second half: the weight pieces of step + 2, then this step's share of the NEXT
+    // run's pieces -- the first A_H0 in step 0 and the rest in step 1, or all of them in step 0 of a paired run
+    constexpr int DMA_MAX = B_PER + A_PER, DMA_PER_G = (DMA_MAX + FN - 1) / FN;
     for (int run = 0; run < total_runs; ++run) {
-        const bool skip_y = tail_short && c_cg == G - 1;
-        const bool tile_end = c_r == 2 && c_cg == G - 1;
+        const bool last_cg = c_cg == G - 1;
+        const bool pair_run = pair && last_cg;                 // this run: taps 0 + 1 in one step, then tap 2
+        const bool tile_end = c_r == 2 && last_cg;
         const int n_r = c_r == 2 ? 0 : c_r + 1;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
+            if (s == 1 && pair_run) continue;
             const int cur = step & 1;
+            // no MFMAs on k 32..63: a half-full last group's step, unless it carries the second tap of a pair there
+            const bool skip_y = tail_short && last_cg && !(pair_run && s == 0);
             // the step being prefetched: the next tap of this run, or the first tap of the next run
-            const int ns = (s + 1) % 3;
+            const int ns = s == 2 ? 0 : ((s == 0 && pair_run) ? 2 : s + 1);
             const int nbuf = s == 2 ? pa ^ 1 : pa;
             const int nr = s == 2 ? n_r : c_r;
             if (s == 2 && tile_end) tile_masks(c_tile + tile_step);       // (masks of a tile past the stream's end are never used)
             const unsigned a_next = a_shift_now(ns);
+            // (paired step: the k 32..63 half is tap 1 of this kernel row -- the fragments one pixel on, k 0..31)
+            const unsigned a_pair = (s == 0 && pair_run) ? a_shift_now(1) + (unsigned)(pa * A_BUF) : 0u;
             // ---- first half: k 0..31 of this step, while its k 32..63 fragments are read and the
             //      fragment addresses of the next step are selected; MFMA chunk g = fragment column g ----
+            auto read_y = [&](int i) __attribute__((always_inline)) -> frag8_t {
+                if (s == 0 && pair_run) {
+                    const unsigned a = ((vmask[i] >> (c_r * 3 + 1)) & 1u) ? a_pair + (unsigned)(i * 2048) : z_addr;
+                    return *(const __attribute__((address_space(3))) frag8_t*)(smem + a);
+                }
+                return read_x(i, 1);
+            };
 #pragma unroll
             for (int g = 0; g < FN; ++g) {
                 // LEAN: the weight fragment of the other k half goes into the registers the chunk before released (one
                 // spare fragment, read first): 6 weight fragments live instead of 10
                 if constexpr (LEAN) wb[(g + FN - 1) % FN] = read_w(cur, 1, (g + FN - 1) % FN);
                 else wb[g] = read_w(cur, 1, g);
-                if (g < FM) { xb[g] = read_x(g, 1); set_a_eff_one(nbuf, nr, ns, g, a_next); }
+                if (g < FM) { xb[g] = read_y(g); set_a_eff_one(nbuf, nr, ns, g, a_next); }
                 if (g == FN - 1) {
 #pragma unroll
-                    for (int i = FN; i < FM; ++i) { xb[i] = read_x(i, 1); set_a_eff_one(nbuf, nr, ns, i, a_next); }
+                    for (int i = FN; i < FM; ++i) { xb[i] = read_y(i); set_a_eff_one(nbuf, nr, ns, i, a_next); }
                 }
                 MDHIP_FENCE();
 #pragma unroll
@@ -568,7 +586,7 @@ conv_v5_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int d = g * DMA_PER_G; d < (g + 1) * DMA_PER_G && d < DMA_MAX; ++d) {
                     if (d < B_PER) dma_b_piece(cur, d);
-                    else if (s == 0 && d - B_PER < A_H0) dma_run_piece(pa ^ 1, d - B_PER);
+                    else if (s == 0 && (d - B_PER < A_H0 || pair_run)) dma_run_piece(pa ^ 1, d - B_PER);
                     else if (s == 1 && A_H0 + d - B_PER < A_PER) dma_run_piece(pa ^ 1, A_H0 + d - B_PER);
                 }
                 MDHIP_FENCE();
@@ -622,8 +640,7 @@ conv_v5_kernel(const ConvArgs p) {
     X(13, 320, 160, 4, 2, 6) \
     X(14, 320, 160, 4, 2, 22) \
     X(15, 320, 160, 4, 2, 2) \
-    X(16, 320, 160, 4, 2, 3) \
-    X(17, 320, 160, 4, 2, 32)
+    X(16, 320, 160, 4, 2, 3)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
@@ -632,7 +649,7 @@ static const ConvCfg g_cfgs5[] = {
     MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
 #undef X
 };
-constexpr int kNumProf5 = 10;
+constexpr int kNumProf5 = 9;
 
 // ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp and the C = 80
 // strip kernel of conv_v5c.cpp (same K order, same results), then the developer variants

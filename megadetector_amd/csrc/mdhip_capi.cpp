@@ -50,6 +50,8 @@ struct PackedConv {
     size_t w_off = 0, b_off = 0;     // byte offsets into the weight arena
     size_t w4_off = 0;               // second packing for the row-patch kernel (0 = none)
     int k_pad4 = 0, groups = 0;
+    size_t w4p_off = 0;              // the same with the half-full last group's taps paired (conv_v5.cpp; 0 = none)
+    int k_pad4p = 0;
     int n_rows = 0, k_pad = 0, cin_pad = 0, kh = 0, kw = 0, c_out = 0, k_real = 0;
     // fp8 form (MDHIP_DTYPE_FP8, 3x3 / stride-1 bottleneck convs): e4m3 weights [n_rows][groups8*9*128], quantised per
     // output channel (wscale[n] = max_k |w[n][k]| / 448); scale_off = device array of n_rows floats holding
@@ -138,6 +140,7 @@ struct mdhip_ctx {
     // C3 blocks whose bottlenecks can run as one launch each (1x1 -> LDS -> 3x3): op indices of the 3x3s per block
     std::vector<std::vector<int>> fuse_groups;
     bool fuse_enabled = true, fuse_suspended = false;
+    bool pair_enabled = true;         // paired taps of a half-full last channel group (conv_v5.cpp); MDHIP_PAIR=0 at create: off
     std::vector<hipEvent_t> events;
     std::vector<mdhip_tuned> tuned;   // measured tile choices (tools/autotune.py)
     // optional event pair around every mdhip_forward (bench.py's live roofline measurement)
@@ -222,6 +225,7 @@ struct Planner {
     size_t cursor = 0;
     std::vector<std::vector<uint16_t>> w_host;   // packed weights per PackedConv
     std::vector<std::vector<uint16_t>> w4_host;  // row-patch packing (empty when not applicable)
+    std::vector<std::vector<uint16_t>> w4p_host; // ... with the last group's taps paired (empty when not applicable)
     std::vector<std::vector<float>> b_host;
     std::vector<std::vector<uint8_t>> w8_host;   // e4m3 packing (empty when the conv has no fp8 form)
     std::vector<int> layer_c, layer_div;
@@ -315,6 +319,24 @@ struct Planner {
                         w4[(size_t)o * pc.k_pad4 + ((ci / 64) * 9 + t) * 64 + (ci % 64)] =
                             w[(size_t)o * pc.k_pad + t * pc.cin_pad + ci];
         }
+        // a last group of at most 32 channels: the paired packing of conv_v5.cpp -- groups 0 .. G-2 as above; last group:
+        // per kernel row r the slabs [ tap (r,0) ch 0..31 | tap (r,1) ch 0..31 ] and [ tap (r,2) ch 0..31 | zeros ]
+        std::vector<uint16_t> w4p;
+        if (!w4.empty() && (pc.cin_pad % 64) != 0 && (pc.cin_pad % 64) <= 32) {
+            const int G = pc.groups, tail = pc.cin_pad % 64;
+            pc.k_pad4p = (9 * (G - 1) + 6) * 64;
+            w4p.assign((size_t)pc.n_rows * pc.k_pad4p, 0);
+            for (int o = 0; o < pc.n_rows; ++o) {
+                const uint16_t* src = &w4[(size_t)o * pc.k_pad4];
+                uint16_t* dst = &w4p[(size_t)o * pc.k_pad4p];
+                std::copy(src, src + (size_t)9 * (G - 1) * 64, dst);
+                for (int r = 0; r < 3; ++r)
+                    for (int sx = 0; sx < 3; ++sx)
+                        for (int ci = 0; ci < tail; ++ci)
+                            dst[((G - 1) * 9 + 2 * r + (sx == 2 ? 1 : 0)) * 64 + (sx == 1 ? 32 : 0) + ci] =
+                                src[((G - 1) * 9 + r * 3 + sx) * 64 + ci];
+            }
+        }
         // fp8 mode: 3x3 convs whose input channel count is a multiple of 16 also get the e4m3 packing of
         // conv_f8.cpp: k = (channel group of 128, tap, channel in group), quantised from the fp32 weights
         std::vector<uint8_t> w8;
@@ -337,6 +359,7 @@ struct Planner {
         ctx->packed.push_back(pc);
         w_host.push_back(std::move(w));
         w4_host.push_back(std::move(w4));
+        w4p_host.push_back(std::move(w4p));
         b_host.push_back(std::move(b));
         w8_host.push_back(std::move(w8));
         return (int)ctx->packed.size() - 1;
@@ -785,6 +808,8 @@ void fill_conv_args(mdhip_ctx* ctx, Op& op, int n, int h, int w, ConvArgs& a) {
     a.wgt4 = pc.w4_off ? (const uint16_t*)(ctx->warena + pc.w4_off) : nullptr;
     a.k_pad4 = pc.k_pad4;
     a.groups = pc.groups;
+    a.wgt4p = (pc.w4p_off && ctx->pair_enabled) ? (const uint16_t*)(ctx->warena + pc.w4p_off) : nullptr;
+    a.k_pad4p = pc.k_pad4p;
     if (ctx->dtype == MDHIP_DTYPE_FP8 && !ctx->calibrating) {
         if (op.f8_in) {
             // the e4m3 tensor lives in the 16-bit tensor's allocation: same pixel pitch, counted in bytes
@@ -1058,6 +1083,7 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
 
     mdhip_ctx* ctx = new mdhip_ctx();
     if (const char* ef = getenv("MDHIP_FUSE")) ctx->fuse_enabled = atoi(ef) != 0;      // A/B measurements
+    if (const char* ep = getenv("MDHIP_PAIR")) ctx->pair_enabled = atoi(ep) != 0;      // A/B measurements, bit-identity test
     ctx->device = device;
     ctx->dtype = dtype;
     ctx->max_batch = max_batch;
@@ -1141,6 +1167,10 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
             ctx->packed[i].w4_off = wcur;
             wcur = align_up(wcur + P.w4_host[i].size() * 2, 256);
         }
+        if (!P.w4p_host[i].empty()) {
+            ctx->packed[i].w4p_off = wcur;
+            wcur = align_up(wcur + P.w4p_host[i].size() * 2, 256);
+        }
         if (!P.w8_host[i].empty()) {
             ctx->packed[i].w8_off = wcur;
             wcur = align_up(wcur + P.w8_host[i].size(), 256);
@@ -1184,6 +1214,8 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
         CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].b_off, P.b_host[i].data(), P.b_host[i].size() * 4, hipMemcpyHostToDevice));
         if (!P.w4_host[i].empty())
             CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].w4_off, P.w4_host[i].data(), P.w4_host[i].size() * 2, hipMemcpyHostToDevice));
+        if (!P.w4p_host[i].empty())
+            CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].w4p_off, P.w4p_host[i].data(), P.w4p_host[i].size() * 2, hipMemcpyHostToDevice));
         if (!P.w8_host[i].empty()) {
             CREATE_TRY(hipMemcpy(ctx->warena + ctx->packed[i].w8_off, P.w8_host[i].data(), P.w8_host[i].size(), hipMemcpyHostToDevice));
             CREATE_TRY(hipMemset(ctx->warena + ctx->packed[i].scale_off, 0, (size_t)ctx->packed[i].n_rows * 4));

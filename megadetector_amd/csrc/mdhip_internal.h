@@ -153,6 +153,12 @@ struct ConvArgs {
     // row-patch direct convolution (conv_v4.cpp): weights packed [n_rows][groups*9*64], k = (cg, r, s, c % 64)
     const uint16_t* wgt4;   // nullptr when the op has no such packing
     int k_pad4, groups;
+    // conv_v5.cpp, layers whose last channel group is at most half full (C_in mod 64 in 8 .. 32: the 160- and 480-channel
+    // bottlenecks): the same packing with the last group's taps PAIRED -- per kernel row r one slab [ tap (r,0) ch 0..31 |
+    // tap (r,1) ch 0..31 ] and one slab [ tap (r,2) ch 0..31 | zeros ], 6 slabs instead of 9 -- so that the group takes two
+    // steps per kernel row instead of three half-empty ones (same MFMA chain per accumulator: same bits).  nullptr = none.
+    const uint16_t* wgt4p;
+    int k_pad4p;
     // fp8 path (conv_f8.cpp; MDHIP_DTYPE_FP8): the input view holds e4m3 bytes (ld_in, C8 then count BYTES and
     // 16-byte chunks = 16 channels), weights packed [n_rows][groups8*9*128] e4m3, k = (channel group of 128, tap,
     // channel in group), `scale` = per-output-channel fp32 factor (activation scale x weight scale) applied to the

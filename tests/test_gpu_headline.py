@@ -455,3 +455,50 @@ def test_eight_wave_tiles_are_bit_identical_to_the_row_segment_kernel(dtype):
                 ctx.set_op_cfg(op, -1)
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_paired_taps_of_a_half_full_channel_group_are_bit_identical(dtype, monkeypatch):
+    """conv_v5.cpp runs the last channel group of the 160- / 480- (and, off the strip kernel, 80-) channel 3x3 convs --
+    32 (16) channels, half a K slab -- with the taps of a kernel row PAIRED in one step (second weight packing `wgt4p`):
+    same operands, same MFMA chain per accumulator as the three half-empty steps -> the same bits as a context created
+    with MDHIP_PAIR=0, for the 8-wave tiles, the two-workgroup tiles and the N = 80 tiles, ragged tiles, with and
+    without residual, several images per batch."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    n, hh, ww = 3, 384, 640
+    imgs = PU.random_images(n, hh, ww, seed=17)
+    out = {}
+    for pair in ('0', '1'):
+        monkeypatch.setenv('MDHIP_PAIR', pair)
+        ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+        try:
+            ctx.set_fuse(False)                              # the 80-channel block through conv_v5 as well
+            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            ctx.forward(n, hh, ww)
+            convs = [o for o in ctx.op_infos() if o['kind'] == 0 and o['ntaps'] == 9 and o['stride'] == 1]
+            tails = [o for o in convs if (o['k'] // 9) % 64 in (16, 32)]
+            assert len(tails) >= 28, len(tails)                  # 4 (C = 80) + 12 (C = 160) + 12 (C = 480)
+            res = []
+            for name in ('v5:run128x160/2x2/0', 'v5:run320x160/4x2/0', 'v5:run256x160/4x2/0', 'v5:run128x80/4x1/0'):
+                cfg = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == name][0]
+                took = 0
+                for o in tails:
+                    if ctx.op_supports_cfg(o['op'], cfg):
+                        ctx.set_op_cfg(o['op'], cfg)
+                        took += 1
+                    else:
+                        ctx.set_op_cfg(o['op'], -1)
+                assert took >= 4, (name, took)
+                ctx.forward(n, hh, ww)
+                ran = [ctx.conv_cfg_name(p['cfg']) for p in ctx.op_infos() if p['op'] in {o['op'] for o in tails}]
+                assert ran.count(name) >= took
+                res.append(ctx.read_predictions(n).copy())
+            for r in res[1:]:
+                np.testing.assert_array_equal(r, res[0])             # every tile of the family: the same bits
+            out[pair] = res[0]
+        finally:
+            ctx.close()
+    assert np.isfinite(out['1']).all()
+    np.testing.assert_array_equal(out['0'], out['1'])

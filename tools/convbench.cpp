@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -169,6 +170,24 @@ int main(int argc, char** argv) {
                     h_w4[(size_t)n * k_pad4 + ((c / 64) * 9 + t) * 64 + (c % 64)] = h_w[(size_t)n * k_pad + t * cin_pad + c];
     }
     uint16_t* d_w4 = nullptr;
+    // the paired packing of conv_v5.cpp for a last group of at most 32 channels (CONVBENCH_PAIR=0: without)
+    uint16_t* d_w4p = nullptr;
+    int k_pad4p = 0;
+    std::vector<uint16_t> h_w4p;
+    if (sh->k == 3 && (cin_pad % 64) != 0 && (cin_pad % 64) <= 32 && !(getenv("CONVBENCH_PAIR") && atoi(getenv("CONVBENCH_PAIR")) == 0)) {
+        const int tail = cin_pad % 64;
+        k_pad4p = (9 * (groups - 1) + 6) * 64;
+        h_w4p.assign((size_t)n_rows * k_pad4p, 0);
+        for (int n = 0; n < n_rows; ++n) {
+            const uint16_t* src = &h_w4[(size_t)n * k_pad4];
+            uint16_t* dst = &h_w4p[(size_t)n * k_pad4p];
+            std::copy(src, src + (size_t)9 * (groups - 1) * 64, dst);
+            for (int r = 0; r < 3; ++r)
+                for (int sx = 0; sx < 3; ++sx)
+                    for (int c = 0; c < tail; ++c)
+                        dst[((groups - 1) * 9 + 2 * r + (sx == 2 ? 1 : 0)) * 64 + (sx == 1 ? 32 : 0) + c] = src[((groups - 1) * 9 + r * 3 + sx) * 64 + c];
+        }
+    }
     uint16_t *d_in, *d_w, *d_res, *d_out, *d_ref, *d_zero;
     float* d_b;
     CK(hipMalloc(&d_in, in_elems * 2 + 4096));
@@ -186,6 +205,10 @@ int main(int argc, char** argv) {
     if (!h_w4.empty()) {
         CK(hipMalloc(&d_w4, h_w4.size() * 2));
         CK(hipMemcpy(d_w4, h_w4.data(), h_w4.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (!h_w4p.empty()) {
+        CK(hipMalloc(&d_w4p, h_w4p.size() * 2));
+        CK(hipMemcpy(d_w4p, h_w4p.data(), h_w4p.size() * 2, hipMemcpyHostToDevice));
     }
 
     {
@@ -248,6 +271,7 @@ int main(int argc, char** argv) {
     a.M = (int)M; a.N = sh->cout; a.n_rows = n_rows; a.k_pad = k_pad; a.ntaps = sh->k * sh->k; a.kw = sh->k;
     a.stride = sh->s; a.pad = pad; a.act = 1; a.out_f32 = 0;
     a.wgt4 = d_w4; a.k_pad4 = k_pad4; a.groups = groups;
+    a.wgt4p = d_w4p; a.k_pad4p = k_pad4p;
     const double flops = 2.0 * (double)M * sh->cout * k_real;
     const size_t dbg_words = 8 * 16 * 4096;
     unsigned long long* d_dbg;
@@ -263,7 +287,7 @@ int main(int argc, char** argv) {
     const ConvArgs a16 = a;
     ConvArgs af8 = a;
     af8.in = (const uint16_t*)d_in8; af8.in_f8 = 1; af8.wgt8 = d_w8; af8.scale = d_scale; af8.k_pad8 = k_pad8; af8.groups8 = groups8;
-    af8.C8 = (sh->cin + 15) / 16; af8.wgt4 = nullptr;
+    af8.C8 = (sh->cin + 15) / 16; af8.wgt4 = nullptr; af8.wgt4p = nullptr;
     for (int cfg : cfgs) {
         const bool is_f8 = cfg <= -801 || (cfg >= 0 && !strncmp(conv_cfg(cfg).name, "f8:", 3));
         if (is_f8 && !want_f8) { printf("  cfg %2d: no fp8 form of this shape\n", cfg); continue; }
