@@ -494,6 +494,7 @@ const Family g_fams[] = {
     {conv5_num_cfgs, conv5_cfg, conv5_supports, conv5_launch, conv5_init, false, -301, false, false},
     {conv6_num_cfgs, conv6_cfg, conv6_supports, conv6_launch, conv6_init, true, -401, false, false},     // the stem kernel: same K order
     {conv8_num_cfgs, conv8_cfg, conv8_supports, conv8_launch, conv8_init, false, -801, true, false},
+    {conv7_num_cfgs, conv7_cfg, conv7_supports, conv7_launch, conv7_init, false, -901, false, false},    // stride-2 row runs: a K order of its own
 };
 constexpr int kNumFams = (int)(sizeof(g_fams) / sizeof(g_fams[0]));
 // family and local id of a global id >= kNumV1

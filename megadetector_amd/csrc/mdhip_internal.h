@@ -237,6 +237,7 @@ struct ConvCfg {
 //             for small launches (conv5s_*, conv_v5s.cpp) are listed behind its own
 //   conv6_* : the stem (3x3 over 16-channel space-to-depth pixels, N = 80) with its weights in registers (conv_v6.cpp)
 //   conv8_* : conv_v5's structure on e4m3 operands with the block-scaled K = 128 MFMA (conv_f8.cpp)
+//   conv7_* : 3x3 / STRIDE 2 with row-run reuse (odd / even input columns in two sub-buffers; conv_v7.cpp); listed last
 // conv_launch returns hipSuccess or the launch error; conv_init raises the dynamic-LDS limits (one-off);
 // conv_cfg_is_bitwise_family is false for kernels whose result equals the others' up to fp32 summation
 // order only.
@@ -282,7 +283,12 @@ struct ConvCfg {
     const ConvCfg& conv8_cfg(int i); \
     bool conv8_supports(int cfg, const ConvArgs& a); \
     hipError_t conv8_launch(int cfg, const ConvArgs& a, hipStream_t s); \
-    hipError_t conv8_init();
+    hipError_t conv8_init(); \
+    int conv7_num_cfgs(); \
+    const ConvCfg& conv7_cfg(int i); \
+    bool conv7_supports(int cfg, const ConvArgs& a); \
+    hipError_t conv7_launch(int cfg, const ConvArgs& a, hipStream_t s); \
+    hipError_t conv7_init();
 namespace st_bf16 {
 MDHIP_CONV_API
 }

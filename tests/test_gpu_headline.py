@@ -502,3 +502,55 @@ def test_paired_taps_of_a_half_full_channel_group_are_bit_identical(dtype, monke
             ctx.close()
     assert np.isfinite(out['1']).all()
     np.testing.assert_array_equal(out['0'], out['1'])
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_stride2_row_run_kernel_against_the_oracle_and_batch_invariant(dtype, monkeypatch):
+    """conv_v7.cpp (3x3 / stride 2 with row-run reuse: odd / even input columns in two sub-buffers, taps in the order
+    0 / 2 / 1 -- a summation order of its own) on the stride-2 convs of the x6 stack whose output rows tile its 320-pixel
+    M tile (Wo = 320 / 160 / 80 / 40 at 384x640: layers 1, 3, 5, 7, 24, 27; ragged last tiles, tiles across images, channel
+    groups 64 + 16 / 2 x 64 + 32 / full): every layer within the layer tolerances of the storage-emulating oracle, close
+    to the implicit-GEMM result, an image's result bit-identical whether it travels alone or in a batch, and -- the arena
+    filled with NaN bytes at creation -- no value read that nobody wrote."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    n, hh, ww = 3, 384, 640
+    imgs = PU.structured_images(n, hh, ww, seed=23)
+    monkeypatch.setenv('MDHIP_ARENA_POISON', '1')
+    ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+    try:
+        v7 = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith('v7:')]
+        assert len(v7) == 1 and not ctx.cfg_is_bitwise(v7[0])
+        gemm = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == 'v2:160x160/2x2'][0]
+        ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+        ctx.forward(n, hh, ww)
+        s2 = [o for o in ctx.op_infos() if o['kind'] == 0 and o['ntaps'] == 9 and o['stride'] == 2]
+        assert len(s2) == 8
+        takers = [o for o in s2 if ctx.op_supports_cfg(o['op'], v7[0])]
+        assert sorted(o['layer'] for o in takers) == [1, 3, 5, 7, 24, 27], [o['name'] for o in takers]
+        for o in s2:
+            ctx.set_op_cfg(o['op'], gemm)
+        ctx.forward(n, hh, ww)
+        ref = ctx.read_predictions(n).copy()
+        for o in takers:
+            ctx.set_op_cfg(o['op'], v7[0])
+        ctx.forward(n, hh, ww)
+        ran = {o['layer']: ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['op'] in {t['op'] for t in takers}}
+        assert set(ran.values()) == {ctx.conv_cfg_name(v7[0])}, ran
+        emulate = True if dtype == 'bf16' else 'fp16'
+        tol = (LAYER_MAX_TOL, LAYER_MEAN_TOL) if dtype == 'bf16' else (F16_LAYER_MAX_TOL, F16_LAYER_MEAN_TOL)
+        worst, e_box, e_conf, pred, _ = _layers_against_oracle(ctx, W, imgs, hh, ww, emulate, *tol)
+        assert np.isfinite(pred).all()
+        d_box = PU.rel_err(pred[..., :4], ref[..., :4])
+        d_conf = float(np.abs(pred[..., 4:] - ref[..., 4:]).max())
+        print('{}: stride-2 row-run kernel on layers {}: worst layer error max {:.2e} mean {:.2e}; against the implicit GEMM: '
+              'box {:.2e}/{:.2e}, conf {:.2e}'.format(dtype, sorted(ran), worst[0], worst[1], d_box[0], d_box[1], d_conf))
+        assert d_box[1] < tol[1] and d_conf < (4e-2 if dtype == 'bf16' else 1e-2)
+        for i in (0, 2):                                                  # batch invariance, bitwise
+            ctx.preprocess([imgs[i]], _identity_geoms([imgs[i]]), hh, ww)
+            ctx.forward(1, hh, ww)
+            assert {ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['op'] in {t['op'] for t in takers}} == {ctx.conv_cfg_name(v7[0])}
+            np.testing.assert_array_equal(ctx.read_predictions(1)[0], pred[i])
+    finally:
+        ctx.close()

@@ -51,6 +51,13 @@ static const Shape kShapes[] = {
     {"l1_s2", 32, 640, 640, 80, 160, 3, 2, false},      // M 3276800 N 160 K 720
     {"l3_s2", 32, 320, 320, 160, 320, 3, 2, false},
     {"l5_s2", 32, 160, 160, 320, 640, 3, 2, false},
+    {"l7_s2", 32, 80, 80, 640, 960, 3, 2, false},       // M 51200 N 960 K 5760
+    {"l24_s2", 32, 160, 160, 320, 320, 3, 2, false},    // M 204800 N 320 K 2880
+    {"l27_s2", 32, 80, 80, 640, 640, 3, 2, false},
+    {"s2a", 3, 10, 80, 96, 160, 3, 2, false},           // stride-2 row-run kernel: Wo = 40, 600 output pixels (ragged last tile, tiles across images), 64 + 32 channels
+    {"s2b", 3, 20, 160, 80, 320, 3, 2, false},          // Wo = 80, 64 + 16 channels, two N tiles
+    {"s2c", 1, 8, 640, 160, 160, 3, 2, false},          // Wo = 320: one output row per tile
+    {"s2d", 2, 48, 320, 128, 160, 3, 2, false},         // Wo = 160, full groups only
     {"p32", 2, 16, 64, 80, 80, 3, 1, true},             // row-patch kernels: short tail group, N = 80
     {"p40", 2, 16, 80, 160, 160, 3, 1, false},          // 64 + 64 + 32 channels
     {"p40b", 3, 8, 40, 96, 200, 3, 1, true},            // 64 + 32 channels, ragged N
