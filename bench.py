@@ -65,9 +65,12 @@ def parse_args():
                     help='only warm-up + timed steps (no per-stage / per-op extras): for rocprofv3 runs')
     ap.add_argument('--cpu-seconds', type=float, default=14.0)
     ap.add_argument('--no-cpu-single-thread', action='store_true', help='skip the one-thread CPU row (one image, ~1 min)')
-    ap.add_argument('--nms-own-stream', action='store_true',
-                    help='NMS + D2H of step i on their own stream next to the forward of step i+1 (round 1); default: on the '
-                         'compute stream behind the forward')
+    ap.add_argument('--nms-inline', action='store_true',
+                    help='NMS + D2H of step i on the compute stream behind the forward (rounds 2-3 default).  Default since '
+                         'round 4: on their own stream next to the forward of step i+1 -- with the banded NMS sort the 32 '
+                         'workgroups are gone before the next forward reaches its 8-wave kernels (+0.4 .. 0.7 %, '
+                         'profiles/r4_bench_nms_stream.txt)')
+    ap.add_argument('--nms-own-stream', action='store_true', help='(the default now; kept so that older command lines still parse)')
     ap.add_argument('--profile-out', default=None, help='write per-op timings (json) here')
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='skip the short legs of the other BASELINE configurations (extra_configs: fp8 batch 64, 1080p video '
@@ -128,7 +131,7 @@ class Workload:
     RING = 16
 
     def __init__(self, torch, weights, dtype, B, S, src, threshold, device, seed_base=0, n_batches=8, host_fed=False,
-                 nms_own_stream=False, graph='off', no_table=False):
+                 nms_own_stream=True, graph='off', no_table=False):
         from megadetector_amd.hip_backend import HipContext
         from megadetector_amd.postprocess import letterbox_geometry
         self.torch, self.B, self.S, self.threshold, self.dtype = torch, B, S, threshold, dtype
@@ -155,8 +158,8 @@ class Workload:
         # with every other blocking stream and measured ~1.5 ms per step slower)
         self.comp_s = torch.cuda.Stream()
         self.compute_stream = self.comp_s.cuda_stream
-        # --nms-own-stream: NMS + D2H of step i on their own stream, next to the forward of step i+1 (the library
-        # alternates between two prediction buffers); ordered with events
+        # NMS + D2H of step i on their own stream, next to the forward of step i+1 (the library alternates between two
+        # prediction buffers); ordered with events.  --nms-inline puts them back on the compute stream
         self.nms_s = torch.cuda.Stream()
         self.fwd_done = [torch.cuda.Event() for _ in range(4)]
         self.nms_done = [None] * 4
@@ -351,7 +354,7 @@ def main():
     yaml = getattr(yolo_yaml, args.model)
     weights = weights_io.synthetic_weights(yaml, seed=0)
     wl = Workload(torch, weights, args.dtype, B, S, args.src, args.threshold, local_rank, seed_base=1000 * rank,
-                  host_fed=args.host_fed, nms_own_stream=args.nms_own_stream, graph=args.graph, no_table=args.no_table)
+                  host_fed=args.host_fed, nms_own_stream=not args.nms_inline, graph=args.graph, no_table=args.no_table)
     ctx, run, stage_live = wl.ctx, wl.run, wl.stage_live
     H0, W0, Hn, Wn = wl.H0, wl.W0, wl.Hn, wl.Wn
     geoms, ptr_lists, compute_stream = wl.geoms, wl.ptr_lists, wl.compute_stream

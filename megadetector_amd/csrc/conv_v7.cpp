@@ -126,27 +126,38 @@ conv_v7_kernel(const ConvArgs p) {
     // first pixel  (8 i + lr) * 2 pixels + jj * 16  -- one lane register, the piece in the scalar part.  The tensor is
     // addressed from its first byte through a descriptor that covers exactly the tensor: a row above the image or past
     // the batch gets an offset outside it and reads zeros.
-    const __amdgpu_buffer_rsrc_t a_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((unsigned)(p.M / p.HoWo) * (unsigned)(p.H * p.W) * (unsigned)p.ld_in * 2u), 0x00020000);
+    // (The descriptor starts at the image of the loader tile's first pixel and covers what is left of the tensor, at most
+    // 2 GiB: a tile spans at most 320 / 40 = 8 images, so no offset depends on the batch size -- whether this kernel takes a
+    // layer must not depend on the batch an image travels in.)
     const unsigned q_off = (unsigned)(lr * 2 * p.ld_in * 2 + jj * 16);
     const unsigned q_stride = (unsigned)(8 * 2 * p.ld_in * 2);           // bytes between a wave's pieces (8 entries = 16 pixels)
     const bool tail_bad = (p.C8 & 7) != 0 && jj >= (p.C8 & 7);           // this lane's chunk of a partly full last group
-    struct RunGeom { unsigned so_o, so_e; bool tail; };                  // scalar byte offsets of the wave's block (kOOB: no such row)
+    // a run as the loader sees it: descriptor of its tile, scalar byte offsets of the wave's block (kOOB: no such row)
+    struct RunGeom { __amdgpu_buffer_rsrc_t rsrc; unsigned so_o, so_e; bool tail; };
     int lg_tile = first_tile, lg_cg = 0, lg_r = 0;
-    int lg_px0 = 0;                                 // input pixel index of (b, 2 oy - 1, 2 ox_w) for the loader's tile (may be negative)
+    int lg_px0 = 0;                                 // input pixel index of (b, 2 oy - 1, 2 ox_w) relative to the descriptor (may be negative)
     bool lg_top = false, lg_ok = false;             // oy > 0 ; the wave's row exists (inside the batch)
+    __amdgpu_buffer_rsrc_t lg_rsrc = b_rsrc;
+    const long long img_bytes = (long long)p.H * p.W * p.ld_in * 2;
+    const int n_img = p.M / p.HoWo;
     auto tile_geom = [&]() __attribute__((always_inline)) {
+        const int m_t = min(lg_tile * BM, p.M - 1);                        // the tile's first output pixel -> its image
+        const int b0 = conv_udiv(m_t, p.HoWo, p.rcp_howo);
+        const long long left = (long long)(n_img - b0) * img_bytes;
+        lg_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in + (long long)b0 * img_bytes), 0,
+                                                    (int)(left > 0x7fffff00LL ? 0x7fffff00LL : left), 0x00020000);
         const int m_w = lg_tile * BM + 40 * wave;                          // first output pixel of the wave's block (wave-uniform)
         lg_ok = m_w < p.M;
-        const int b = conv_udiv(m_w, p.HoWo, p.rcp_howo);
+        const int b = conv_udiv(min(m_w, p.M - 1), p.HoWo, p.rcp_howo);
         const int rem = m_w - b * p.HoWo;
         const int oy = conv_udiv(rem, p.Wo, p.rcp_wo);
         const int ox = rem - oy * p.Wo;
         lg_top = oy > 0;
-        lg_px0 = (b * p.H + 2 * oy - 1) * p.W + 2 * ox;
+        lg_px0 = ((b - b0) * p.H + 2 * oy - 1) * p.W + 2 * ox;
     };
     auto run_geom = [&]() __attribute__((always_inline)) -> RunGeom {
         RunGeom g;
+        g.rsrc = lg_rsrc;
         const bool ok = lg_ok && (lg_r > 0 || lg_top);
         const unsigned base = (unsigned)(lg_px0 + lg_r * p.W) * (unsigned)p.ld_in * 2u + (unsigned)(lg_cg * 128);
         g.so_e = ok ? base : kOOB;
@@ -164,7 +175,7 @@ conv_v7_kernel(const ConvArgs p) {
         }
     };
     // piece i of a sub-buffer (sub = O_OFF / E_OFF) of the run with geometry g
-    auto dma_run_piece = [&](int sub, unsigned so_base, bool tail, int i) __attribute__((always_inline)) {
+    auto dma_run_piece = [&](int sub, const __amdgpu_buffer_rsrc_t& a_rsrc, unsigned so_base, bool tail, int i) __attribute__((always_inline)) {
         unsigned so = so_base + (unsigned)i * q_stride;
         asm volatile("" : "+s"(so));
         unsigned voff = q_off + so;                                       // (so_base = kOOB: far outside the descriptor)
@@ -287,8 +298,8 @@ conv_v7_kernel(const ConvArgs p) {
     RunGeom g_cur = run_geom();
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        dma_run_piece(O_OFF, g_cur.so_o, g_cur.tail, i);
-        dma_run_piece(E_OFF, g_cur.so_e, g_cur.tail, i);
+        dma_run_piece(O_OFF, g_cur.rsrc, g_cur.so_o, g_cur.tail, i);
+        dma_run_piece(E_OFF, g_cur.rsrc, g_cur.so_e, g_cur.tail, i);
     }
     run_next();
     RunGeom g_nxt = run_geom();                      // the run after the one being consumed
@@ -365,9 +376,9 @@ conv_v7_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int d = g * DMA_PER_G; d < (g + 1) * DMA_PER_G && d < DMA_MAX; ++d) {
                     if (d < B_PER) dma_b_piece(cur, d);
-                    else if (st == 0 && E_H0 + d - B_PER < A_PER) dma_run_piece(E_OFF, g_cur.so_e, g_cur.tail, E_H0 + d - B_PER);
-                    else if (st == 1) dma_run_piece(O_OFF, g_nxt.so_o, g_nxt.tail, d - B_PER);
-                    else if (st == 2 && d - B_PER < E_H0) dma_run_piece(E_OFF, g_nxt.so_e, g_nxt.tail, d - B_PER);
+                    else if (st == 0 && E_H0 + d - B_PER < A_PER) dma_run_piece(E_OFF, g_cur.rsrc, g_cur.so_e, g_cur.tail, E_H0 + d - B_PER);
+                    else if (st == 1) dma_run_piece(O_OFF, g_nxt.rsrc, g_nxt.so_o, g_nxt.tail, d - B_PER);
+                    else if (st == 2 && d - B_PER < E_H0) dma_run_piece(E_OFF, g_nxt.rsrc, g_nxt.so_e, g_nxt.tail, d - B_PER);
                 }
                 MDHIP_FENCE();
             }
@@ -405,12 +416,12 @@ bool conv7_supports(int cfg, const ConvArgs& a) {
     // 3x3 / stride 2 / pad 1 over an even-sized map whose output rows tile the 320-pixel M tile exactly (Wo = 40, 80, 160,
     // 320) and hold whole 40-entry wave blocks; every output channel of every N tile exists (no channel test on stores);
     // activated 16-bit outputs, no residual (the stride-2 convs of the YOLOv5 family have none); at least one full
-    // 64-channel group; the input tensor inside the 32-bit offset range of the run loader's single descriptor
+    // 64-channel group; the (at most eight) images a tile spans inside the 31-bit offset range of the run loader's descriptor
     return cfg == 0 && !a.in_f8 && !a.out_f8 && !a.out_f32 && a.res == nullptr && a.act == 1 && a.wgt4 != nullptr &&
            a.ntaps == 9 && a.kw == 3 && a.stride == 2 && a.pad == 1 && a.H == 2 * a.Ho && a.W == 2 * a.Wo &&
            a.Wo >= 40 && (kBM7 % a.Wo) == 0 && (a.Wo % 40) == 0 && a.HoWo == a.Ho * a.Wo && (a.M % a.HoWo) == 0 &&
            a.C8 >= 8 && (a.N % kBN7) == 0 && a.N == a.n_rows &&
-           ((long long)(a.M / a.HoWo) * a.H * a.W + 4LL * a.W + 64) * a.ld_in * 2 < 0x7fffff00LL;
+           (9LL * a.H * a.W + 4LL * a.W + 64) * a.ld_in * 2 < 0x7fffff00LL;      // (per image: nothing here depends on the batch)
 }
 
 hipError_t conv7_launch(int cfg, const ConvArgs& a, hipStream_t s) {

@@ -397,16 +397,26 @@ class HIPDetector:
             ev = torch.cuda.Event()
             ev.record(comp)
             pl['consumed'][k] = ev
-            # NMS + D2H behind the forward on the compute stream.  (Round 1 ran them on their own stream next to the
-            # following batch's forward; measured in round 2: the 1024-thread NMS workgroups keep the persistent conv
-            # workgroups off their CUs, the forward slows by more than the NMS costs in line: 37.6 vs 37.2 ms / step.)
+            # NMS + D2H on their own stream, next to the following batch's letterbox and first layers (the library
+            # alternates between two prediction buffers; the forward that reuses a buffer waits for the NMS that read it).
+            # History: own stream in round 1; in line behind the forward in rounds 2-3 (the 1024-thread NMS workgroups kept
+            # the persistent conv workgroups off their CUs: 37.6 vs 37.2 ms / step); since round 4 the NMS sorts only the
+            # confidence band it needs and is gone before the next forward reaches its 8-wave kernels: own stream again
+            # (+0.4 .. 0.7 % at batch 32, profiles/r4_bench_nms_stream.txt).
+            prev = pl['nms_done'][(pl['count'] - 3) % 4]             # (count was incremented above: the batch two before this one)
+            if prev is not None:
+                comp.wait_event(prev)
             if augment:
                 ctx.forward_tta(n, h, w, stream=comp.cuda_stream)
             else:
                 ctx.forward(n, h, w, stream=comp.cuda_stream)
-            ctx.nms_enqueue(n, detection_threshold, self._nms_iou(), 300, slot=nms_slot, stream=comp.cuda_stream)
+            fwd_done = torch.cuda.Event()
+            fwd_done.record(comp)
+            nms_s = pl['nms_s']
+            nms_s.wait_event(fwd_done)
+            ctx.nms_enqueue(n, detection_threshold, self._nms_iou(), 300, slot=nms_slot, stream=nms_s.cuda_stream)
             done = torch.cuda.Event()
-            done.record(comp)
+            done.record(nms_s)
             pl['nms_done'][nms_slot] = done
         return {'items': group_items, 'h': h, 'w': w, 'slot': nms_slot, 'copied': pl['copied'][k], 'images': images}
 

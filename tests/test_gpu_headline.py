@@ -90,10 +90,18 @@ def force_table_tiles(ctx, n, h, w, batch=32, shape=(1280, 1280)):
             missing.append((o['name'], o['n'], o['k'], m_target))
             continue
         cfg = by_name.get(e.get('name'), e['cfg'])
-        assert ctx.op_supports_cfg(o['op'], cfg), (o['name'], e.get('name'))
+        if not ctx.op_supports_cfg(o['op'], cfg):
+            # A benchmarked configuration with a shape condition the reduced test shape does not meet (the stride-2 row-run
+            # kernel needs output rows of 40 .. 320 pixels: 40 at 1280x1280 is 20 at 640x640).  The op keeps the table's
+            # own choice here and is reported as None; the full-size tests (same shape as the bench) force it.
+            assert (h, w) != tuple(shape) and ctx.conv_cfg_name(cfg).startswith('v7:'), (o['name'], e.get('name'))
+            ctx.set_op_cfg(o['op'], -1)
+            forced[o['op']] = None
+            continue
         ctx.set_op_cfg(o['op'], cfg)
         forced[o['op']] = ctx.conv_cfg_name(cfg)
     assert not missing, 'no table entry for these ops at batch {} / {}x{}: {}'.format(batch, shape[0], shape[1], missing)
+    assert sum(1 for v in forced.values() if v is None) <= 2, forced
     return forced
 
 
@@ -102,7 +110,8 @@ def assert_forced_equal_benchmarked(ctx, forced, dtype, batch, shape):
     convs = [o for o in ctx.op_infos() if o['kind'] == 0]
     want = bench_tiles(dtype, batch, shape)
     assert len(want) == len(convs), (len(want), len(convs))
-    diff = [(o['name'], forced[o['op']], w) for o, w in zip(convs, want) if w != 'fused' and forced[o['op']] != w]
+    diff = [(o['name'], forced[o['op']], w) for o, w in zip(convs, want)
+            if w != 'fused' and forced[o['op']] is not None and forced[o['op']] != w]
     assert not diff, 'forced tile != tile of the benchmarked step (op, forced, benchmarked): {}'.format(diff[:8])
     fused = [o['name'] for o, w in zip(convs, want) if w == 'fused']
     assert all('C3.m' in s and 'cv1' in s for s in fused), fused
@@ -121,6 +130,8 @@ def _ran_tiles(ctx, forced):
             nxt = infos[k + 1]
             assert 'L2 C3.m' in o['name'] and 'cv1' in o['name'] and ctx.conv_cfg_name(nxt['cfg']).startswith('v5:strip'), o
             ran[o['op']] = forced[o['op']]
+        elif forced.get(o['op'], '') is None:
+            ran[o['op']] = None                                   # not forced at this test shape (force_table_tiles)
         else:
             ran[o['op']] = ctx.conv_cfg_name(o['cfg'])
     return ran
@@ -166,7 +177,7 @@ def test_headline_topology_every_layer_with_the_benchmarked_tiles(dtype):
         ctx.forward(2, HH, WW)
         ran = _ran_tiles(ctx, forced)
         assert ran == forced                                         # the ops really ran the benchmarked kernels
-        used = sorted(set(ran.values()))
+        used = sorted(set(v for v in ran.values() if v is not None))
         print('{}: benchmarked tile configurations in use: {}'.format(dtype, used))
         # kernel families of the benchmarked step: row-segment (v5 / v6), second-generation implicit GEMM (v2),
         # first-generation implicit GEMM (stem, Detect, N = 80 layers)
@@ -508,7 +519,7 @@ def test_paired_taps_of_a_half_full_channel_group_are_bit_identical(dtype, monke
 def test_stride2_row_run_kernel_against_the_oracle_and_batch_invariant(dtype, monkeypatch):
     """conv_v7.cpp (3x3 / stride 2 with row-run reuse: odd / even input columns in two sub-buffers, taps in the order
     0 / 2 / 1 -- a summation order of its own) on the stride-2 convs of the x6 stack whose output rows tile its 320-pixel
-    M tile (Wo = 320 / 160 / 80 / 40 at 384x640: layers 1, 3, 5, 7, 24, 27; ragged last tiles, tiles across images, channel
+    M tile (Wo = 160 / 80 / 40 / 40 at 384x640: layers 1, 3, 5, 24; ragged last tiles, tiles across images, channel
     groups 64 + 16 / 2 x 64 + 32 / full): every layer within the layer tolerances of the storage-emulating oracle, close
     to the implicit-GEMM result, an image's result bit-identical whether it travels alone or in a batch, and -- the arena
     filled with NaN bytes at creation -- no value read that nobody wrote."""
@@ -528,7 +539,7 @@ def test_stride2_row_run_kernel_against_the_oracle_and_batch_invariant(dtype, mo
         s2 = [o for o in ctx.op_infos() if o['kind'] == 0 and o['ntaps'] == 9 and o['stride'] == 2]
         assert len(s2) == 8
         takers = [o for o in s2 if ctx.op_supports_cfg(o['op'], v7[0])]
-        assert sorted(o['layer'] for o in takers) == [1, 3, 5, 7, 24, 27], [o['name'] for o in takers]
+        assert sorted(o['layer'] for o in takers) == [1, 3, 5, 24], [o['name'] for o in takers]      # (layers 7 / 27: 20 columns here)
         for o in s2:
             ctx.set_op_cfg(o['op'], gemm)
         ctx.forward(n, hh, ww)

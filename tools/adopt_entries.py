@@ -31,13 +31,15 @@ def main():
     for line in open(a.table):
         m = re.match(r'(.{34}) M=\s*(\d+) N=\s*(\d+) K=\s*(\d+) .*?\| (.*)$', line)
         if m:
-            rows[(int(m.group(2)), int(m.group(3)), int(m.group(4)))] = [float(v) for v in m.group(5).split()]
+            # (a stride-2 3x3 conv and a stride-1 one can share M, N and K: the op name tells them apart)
+            stride = 2 if re.search(r'conv \dx\ds2', m.group(1)) else 1
+            rows[(int(m.group(2)), int(m.group(3)), int(m.group(4)), stride)] = [float(v) for v in m.group(5).split()]
     adopted = kept = 0
     for e in json.load(open(a.retuned))['entries']:
         k = key(e)
         if not str(e.get('name', '')).startswith(a.prefix) or k not in old or old[k].get('name') == e.get('name'):
             continue
-        tf = rows.get((e['m'], e['n'], e['k']))
+        tf = rows.get((e['m'], e['n'], e['k'], e['stride']))
         if not tf or old[k].get('name') not in names:
             continue
         t_new, t_old = tf[names.index(e['name'])], tf[names.index(old[k]['name'])]
