@@ -71,6 +71,11 @@ def parse_args():
                          'workgroups are gone before the next forward reaches its 8-wave kernels (+0.4 .. 0.7 %, '
                          'profiles/r4_bench_nms_stream.txt)')
     ap.add_argument('--nms-own-stream', action='store_true', help='(the default now; kept so that older command lines still parse)')
+    ap.add_argument('--pre-own-stream', action='store_true',
+                    help='letterbox of step i+1 on its own stream next to the forward of step i, behind that forward\'s stem '
+                         '(mdhip_preprocess waits for it inside the library).  Measured in round 4: 1015.5 against 1021.5 '
+                         'images/s with the letterbox on the compute stream (profiles/r4_bench_pre_stream.txt) -- its '
+                         'workgroups keep the 8-wave conv workgroups off their CUs; off by default')
     ap.add_argument('--profile-out', default=None, help='write per-op timings (json) here')
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='skip the short legs of the other BASELINE configurations (extra_configs: fp8 batch 64, 1080p video '
@@ -131,7 +136,7 @@ class Workload:
     RING = 16
 
     def __init__(self, torch, weights, dtype, B, S, src, threshold, device, seed_base=0, n_batches=8, host_fed=False,
-                 nms_own_stream=True, graph='off', no_table=False):
+                 nms_own_stream=True, pre_own_stream=False, graph='off', no_table=False):
         from megadetector_amd.hip_backend import HipContext
         from megadetector_amd.postprocess import letterbox_geometry
         self.torch, self.B, self.S, self.threshold, self.dtype = torch, B, S, threshold, dtype
@@ -161,6 +166,12 @@ class Workload:
         # NMS + D2H of step i on their own stream, next to the forward of step i+1 (the library alternates between two
         # prediction buffers); ordered with events.  --nms-inline puts them back on the compute stream
         self.nms_s = torch.cuda.Stream()
+        # (--pre-own-stream: the letterbox of step i + 1 on its own stream too, next to the forward of step i: the library makes
+        # it wait for that forward's stem -- the only reader of the network input -- and the forward of step i + 1 waits for
+        # it here.  Measured slower than in line: off by default)
+        self.pre_s = torch.cuda.Stream()
+        self.pre_own_stream = pre_own_stream and not host_fed
+        self.pre_done = {}
         self.fwd_done = [torch.cuda.Event() for _ in range(4)]
         self.nms_done = [None] * 4
         # live per-stage timing (roofline.stages): event pairs on the stream each stage is launched on
@@ -230,13 +241,28 @@ class Workload:
             self.consumed[k].record(comp_s)
             self.forward_and_nms(i)
             return
-        if self.stage_live['on']:
-            self.ev_pre[i % self.RING][0].record(comp_s)
-        ctx.preprocess(self.ptr_lists[i % self.n_batches], self.geoms, self.Hn, self.Wn, stream=self.compute_stream)
-        if self.stage_live['on']:
-            self.ev_pre[i % self.RING][1].record(comp_s)
-            self.stage_live['steps'].append(i)
+        if not self.pre_own_stream:
+            self.do_preprocess(i, comp_s)
+            self.forward_and_nms(i)
+            return
+        if i not in self.pre_done:                      # the first step of a run(): nothing enqueued it yet
+            self.do_preprocess(i, self.pre_s)
+        comp_s.wait_event(self.pre_done.pop(i))
         self.forward_and_nms(i)
+        if i + 1 < self.run_steps:                      # exactly K letterbox launches for K steps
+            self.do_preprocess(i + 1, self.pre_s)
+
+    def do_preprocess(self, i, stream):
+        torch = self.torch
+        if self.stage_live['on']:
+            self.ev_pre[i % self.RING][0].record(stream)
+        self.ctx.preprocess(self.ptr_lists[i % self.n_batches], self.geoms, self.Hn, self.Wn, stream=stream.cuda_stream)
+        if self.stage_live['on']:
+            self.ev_pre[i % self.RING][1].record(stream)
+            self.stage_live['steps'].append(i)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.pre_done[i] = ev
 
     def collect(self, i):
         from megadetector_amd.postprocess import format_detections
@@ -249,6 +275,8 @@ class Workload:
         # thread (formatting, a descheduled process) does not leave the GPU idle
         last = None
         depth = 2
+        self.run_steps = n_steps
+        self.pre_done = {}
         for i in range(n_steps):
             self.enqueue(i)
             if i >= depth:
@@ -354,7 +382,8 @@ def main():
     yaml = getattr(yolo_yaml, args.model)
     weights = weights_io.synthetic_weights(yaml, seed=0)
     wl = Workload(torch, weights, args.dtype, B, S, args.src, args.threshold, local_rank, seed_base=1000 * rank,
-                  host_fed=args.host_fed, nms_own_stream=not args.nms_inline, graph=args.graph, no_table=args.no_table)
+                  host_fed=args.host_fed, nms_own_stream=not args.nms_inline, pre_own_stream=args.pre_own_stream, graph=args.graph,
+                  no_table=args.no_table)
     ctx, run, stage_live = wl.ctx, wl.run, wl.stage_live
     H0, W0, Hn, Wn = wl.H0, wl.W0, wl.Hn, wl.Wn
     geoms, ptr_lists, compute_stream = wl.geoms, wl.ptr_lists, wl.compute_stream

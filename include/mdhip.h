@@ -108,7 +108,11 @@ const char* mdhip_last_error(mdhip_ctx* ctx);
 /* Replaces letterbox() + HWC->CHW + float() + /255 (pytorch_detector.py:1104-1109,
  * :1283-1310).  images[i]: HWC uint8 RGB, src_h x src_w, host or device memory
  * (host images are copied to a device staging area first).  Output: the context's network input,
- * n x out_h x out_w.  out_h/out_w must be multiples of the model's largest stride. */
+ * n x out_h x out_w.  out_h/out_w must be multiples of the model's largest stride.
+ * Streams: the call may be enqueued on another stream than the forwards -- it first makes its stream wait
+ * (hipStreamWaitEvent, inside the library) for the last mdhip_forward / mdhip_forward_tta enqueued before it to have read
+ * the network input (the stem), so the letterbox of batch i + 1 can run next to the rest of forward i; the forward of
+ * batch i + 1 must then be ordered behind this call by the caller (an event), as bench.py and the detector do. */
 int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_letterbox* geom,
                      int n, int out_h, int out_w, void* hip_stream);
 

@@ -166,6 +166,11 @@ struct mdhip_ctx {
     std::map<std::tuple<int, int, int, int>, GraphSlot> graphs;
     static constexpr int kMaxGraphs = 32;                 // cached executables (letterbox shapes x batch sizes x 2 buffers)
     long long graph_clock = 0;
+    // recorded on the forward's stream behind the last op that reads the network input (the stem, op 0): a following
+    // mdhip_preprocess -- possibly on ANOTHER stream, next to the rest of this forward -- waits for it before it overwrites
+    // the input tensor
+    hipEvent_t input_free = nullptr;
+    bool input_free_valid = false;
 };
 
 namespace {
@@ -1195,6 +1200,7 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     CREATE_TRY(hipMemset(ctx->warena, 0, 256));
     CREATE_TRY(hipHostMalloc((void**)&ctx->geom_host, (size_t)4 * max_batch * sizeof(LetterboxDev), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreateWithFlags(&ctx->geom_ev[i], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->input_free, hipEventDisableTiming));
     for (int i = 0; i < MDHIP_NMS_SLOTS; ++i) {
         CREATE_TRY(hipHostMalloc((void**)&ctx->nms_host_out[i], (size_t)max_batch * kNmsMaxDet * 6 * 4, hipHostMallocDefault));
         CREATE_TRY(hipHostMalloc((void**)&ctx->nms_host_cnt[i], (size_t)max_batch * 4, hipHostMallocDefault));
@@ -1247,6 +1253,7 @@ void mdhip_destroy(mdhip_ctx* ctx) {
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->geom_host) (void)hipHostFree(ctx->geom_host);
     for (int i = 0; i < 4; ++i) if (ctx->geom_ev[i]) (void)hipEventDestroy(ctx->geom_ev[i]);
+    if (ctx->input_free) (void)hipEventDestroy(ctx->input_free);
     for (int i = 0; i < MDHIP_NMS_SLOTS; ++i) {
         if (ctx->nms_host_out[i]) (void)hipHostFree(ctx->nms_host_out[i]);
         if (ctx->nms_host_cnt[i]) (void)hipHostFree(ctx->nms_host_cnt[i]);
@@ -1305,6 +1312,8 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
         g[i].src = (const uint8_t*)(ctx->stage + cur);
         cur += align_up(bytes, 256);
     }
+    // the forward that still reads the input tensor (its stem) comes first, whatever stream it runs on
+    if (ctx->input_free_valid) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->input_free, 0));
     // geometry goes through a 4-deep pinned ring so that the call never blocks on the stream
     const int slot = ctx->geom_slot;
     ctx->geom_slot = (slot + 1) & 3;
@@ -1369,9 +1378,18 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
             }
         }
     }
-    if (!launched)
-        for (Op& op : ctx->ops)
-            if (int rc = run_op(ctx, op, n, h, w, s)) return rc;
+    if (!launched) {
+        for (size_t oi = 0; oi < ctx->ops.size(); ++oi) {
+            if (int rc = run_op(ctx, ctx->ops[oi], n, h, w, s)) return rc;
+            if (oi == 0) {                                   // (the planner lets only layer 0 read the network input)
+                HIP_TRY(ctx, hipEventRecord(ctx->input_free, s));
+                ctx->input_free_valid = true;
+            }
+        }
+    } else {
+        HIP_TRY(ctx, hipEventRecord(ctx->input_free, s));
+        ctx->input_free_valid = true;
+    }
     if (ctx->time_forward) {
         HIP_TRY(ctx, hipEventRecord(ctx->fwd_ev[slot][1], s));
         ++ctx->fwd_count;
@@ -1437,6 +1455,8 @@ int mdhip_forward_tta(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
         out_off += t.keep_to - t.keep_from;
     }
     HIP_TRY(ctx, hipMemcpyAsync(in, orig, in_bytes, hipMemcpyDeviceToDevice, s));       // `input` holds the batch again
+    HIP_TRY(ctx, hipEventRecord(ctx->input_free, s));
+    ctx->input_free_valid = true;
     ctx->cur_tta = DecodeTta();
     ctx->last_n = n;
     ctx->last_h = h;
@@ -1473,6 +1493,7 @@ int mdhip_calibrate(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     for (Op& op : ctx->ops) op.memo_cfg = -1;
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->input_free_valid = false;                      // (the stream is idle: nothing to wait for)
     for (Op& op : ctx->ops) {
         if (!op.f8_out) continue;
         float m = 0.f;
@@ -1575,6 +1596,7 @@ int mdhip_forward_timed(mdhip_ctx* ctx, int n, int h, int w, float* ms, void* hi
         HIP_TRY(ctx, hipEventRecord(ctx->events[i + 1], s));
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->input_free_valid = false;
     for (size_t i = 0; i < ctx->ops.size(); ++i)
         HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->events[i], ctx->events[i + 1]));
     ctx->last_n = n;

@@ -387,9 +387,12 @@ class HIPDetector:
                     stage[off:off + im.nbytes].copy_(torch.from_numpy(flat), non_blocking=True)
                 pl['copied'][k].record(pl['copy_s'])
             comp = pl['comp_s']
-            comp.wait_event(pl['copied'][k])
             base = stage.data_ptr()
             ctx = self._ctx
+            comp.wait_event(pl['copied'][k])
+            # (the letterbox on the copy stream next to the previous batch's forward -- mdhip_preprocess waits for that
+            # forward's stem inside the library -- was measured with bench.py --pre-own-stream: 0.6 % slower, its workgroups
+            # keep the 8-wave conv workgroups off their CUs; it stays on the compute stream)
             ctx.preprocess([base + off for off in offs], geoms, h, w, stream=comp.cuda_stream)
             if self._fp8_pending:
                 ctx.calibrate(n, h, w, stream=comp.cuda_stream)

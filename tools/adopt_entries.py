@@ -50,9 +50,27 @@ def main():
         else:
             kept += 1
             print('keep   M={:8d} N={:4d} K={:5d} batch {:2d}: {} {:.1f} vs {} {:.1f} TFLOP/s'.format(e['m'], e['n'], e['k'], k[0], old[k]['name'], t_old, e['name'], t_new))
+    # one kernel family per layer geometry and image shape over ALL batch sizes (an image's result must not depend on the
+    # batch it travels in): the entries of the other batches follow the entry of the largest batch where that one now is
+    # of the --prefix family (the only configuration of that family there is; their own measurements no longer apply)
+    geo = lambda e: (e['n'], e['k'], e['ntaps'], e['stride'], e['has_res'], round(e['m'] / max(1, int(e.get('batch', 32)))))
+    lead = {}
+    for e in old.values():
+        g = geo(e)
+        if g not in lead or int(e.get('batch', 32)) > int(lead[g].get('batch', 32)):
+            lead[g] = e
+    moved = 0
+    for e in old.values():
+        top = lead[geo(e)]
+        if str(top.get('name', '')).startswith(a.prefix) and e.get('name') != top['name']:
+            e['name'], e['cfg'] = top['name'], top['cfg']
+            e.pop('ms', None)
+            e.pop('tflops', None)
+            e['note'] = 'family of the batch-{} entry'.format(top.get('batch', 32))
+            moved += 1
     shipped['entries'] = list(old.values())
     json.dump(shipped, open(a.shipped, 'w'), indent=1, sort_keys=True)
-    print('{} adopted, {} kept'.format(adopted, kept))
+    print('{} adopted, {} kept, {} entries of other batch sizes moved to the family of their layer'.format(adopted, kept, moved))
 
 
 def shipped_name(shipped, k):
