@@ -19,6 +19,13 @@
 //     step -- the next run's E pieces follow in the second halves of that step and of the next run's first one.  Every
 //     piece still has at least one whole step between its issue and the barrier that publishes it.
 //
+// (Round 4, built, measured, removed: a last channel group of at most 16 channels -- C_in = 80, layer 1, nine steps with a
+// quarter of their k filled -- as ONE run with its nine taps four to a step (the 16 channels of the three kernel rows side
+// by side in the 128-byte rows, the lanes of k 0..15 and k 16..31 of a k half reading different taps): 12 steps per tile
+// instead of 18, correct on every shape, and 3 % SLOWER on layer 1 (616 against 634 TFLOP/s; profiles/
+// r4_convbench_stride2_fat_tail.txt) -- that layer is bound by its 2.1 GB of input through L2 and by its epilogue, not
+// by its step count.)
+//
 // No per-tap zero rows for the left border except tap 0 at ox = 0 and kernel row 0 at oy = 0 (three bits per pixel:
 // in range, oy > 0, ox > 0); the right and bottom borders never leave the image (H = 2 Ho, W = 2 Wo, pad 1).
 // Everything else -- 8 waves with 80x80 wave tiles, persistent XCD-local tile streams, weight slabs through a two-stage

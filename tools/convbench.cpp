@@ -58,6 +58,8 @@ static const Shape kShapes[] = {
     {"s2b", 3, 20, 160, 80, 320, 3, 2, false},          // Wo = 80, 64 + 16 channels, two N tiles
     {"s2c", 1, 8, 640, 160, 160, 3, 2, false},          // Wo = 320: one output row per tile
     {"s2d", 2, 48, 320, 128, 160, 3, 2, false},         // Wo = 160, full groups only
+    {"s2e", 3, 14, 80, 72, 160, 3, 2, false},           // Wo = 40, 64 + 8 channels (one chunk in the last group), ragged, tiles across images
+    {"s2f", 2, 6, 640, 208, 160, 3, 2, false},          // Wo = 320, 3 x 64 + 16 channels
     {"p32", 2, 16, 64, 80, 80, 3, 1, true},             // row-patch kernels: short tail group, N = 80
     {"p40", 2, 16, 80, 160, 160, 3, 1, false},          // 64 + 64 + 32 channels
     {"p40b", 3, 8, 40, 96, 200, 3, 1, true},            // 64 + 32 channels, ragged N
