@@ -50,3 +50,8 @@ left && timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no
 left && timeout 300 python tests/accuracy_report.py --x6 > $O/accuracy_x6.txt 2>&1
 stamp "all done"
 ls -laR $O > $O/ls.log
+# ---- the multi-rank code path of bench.py on this one GPU (gloo test hook), the end-to-end feed on JPEG files ----
+left && MDHIP_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py --gpus 2 --batch 8 --steps 30 --warmup 5 > $O/bench_2rank_one_gpu_gloo.log 2>&1
+left && timeout 400 python tools/e2e_feed_bench.py --n 4096 --workers 16,24 --out $O/e2e_feed.json > $O/e2e_feed.log 2>&1
+stamp "2-rank + feed"
