@@ -54,4 +54,12 @@ ls -laR $O > $O/ls.log
 left && MDHIP_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 2 --batch 8 --steps 30 --warmup 5 > $O/bench_2rank_one_gpu_gloo.log 2>&1
 left && timeout 400 python tools/e2e_feed_bench.py --n 4096 --workers 16,24 --out $O/e2e_feed.json > $O/e2e_feed.log 2>&1
+# the NUMA placement code on this box's topology (8 GPUs asked for: what the planner does with the GPUs it cannot see)
+left && python -c "
+from megadetector_amd import placement as P
+t = P.read_topology(8); print('topology', t)
+plan = P.plan(8, t); print('cpus per worker', [len(c) for c in plan]); print('disjoint', len(set(c for w in plan for c in w)) == sum(len(c) for c in plan))
+print('pin_worker(3, 8) ->', len(P.pin_worker(3, 8, verbose=True)), 'cpus')
+import os; print('affinity of every thread now', sorted({len(os.sched_getaffinity(int(t))) for t in os.listdir('/proc/self/task')}))
+" > $O/placement_box.txt 2>&1
 stamp "2-rank + feed"
