@@ -76,8 +76,14 @@ constexpr int v5_waves_per_simd(int bm, int bn, int nw) {
 #define MDHIP_DMA16(rsrc, lptr, voff, soff) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr), 16, (voff), (soff), 0, 0)
 
-// PROF bits (developer builds only): 1 = s_memtime stamps, 2 = no stores, 4 = no SiLU, 16 = no DMA in the steady state
-template <int BM, int BN, int WM, int WN, int PROF = 0>
+// PROF bits (developer builds only): 1 = s_memtime stamps, 2 = no stores, 4 = no SiLU, 16 = no DMA in the steady state,
+// 32 = no tap-validity selects (timing experiment: wrong at image borders), 64 = no paired / short last group
+// TAIL: what the last channel group looks like, fixed at compile time so that the steps of the full groups carry no
+// test for it (every instruction between two MFMA chunks is matrix-pipe idle time in the lock-stepped tiles; the run-time
+// tests cost 4 % on the 320-channel layers, which have no tail at all): 0 = every group is full (or more than half full),
+// 1 = a last group of <= 32 channels (its k 32..63 MFMAs are skipped), 2 = that group with paired taps,
+// -1 = decided at run time (developer variants)
+template <int BM, int BN, int WM, int WN, int PROF = 0, int TAIL = -1>
 __global__ void __launch_bounds__(WM * WN * 64, v5_waves_per_simd(BM, BN, WM * WN))
 conv_v5_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -94,6 +100,11 @@ conv_v5_kernel(const ConvArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lds_char* const smem = (lds_char*)smem_generic;
+    // Fragment reads address LDS by NUMBER: the kernel has no static LDS, so the dynamic block starts at byte 0, but the
+    // compiler only learns that at link time and emits `v_add_u32 v, <base>, v` in front of every ds_read whose address is
+    // formed as smem + offset -- ten VALU instructions a step between the MFMA chunks (checked once below)
+    auto lds_at = [](unsigned off) __attribute__((always_inline)) { return (const lds_char*)off; };
+    if ((unsigned)(uintptr_t)smem != 0u) __builtin_trap();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,7 +126,8 @@ conv_v5_kernel(const ConvArgs p) {
     const int G = p.groups;                       // 64-channel groups (the last one may be half full)
     const int runs_per_tile = 3 * G;              // (channel group, kernel row) pairs
     // a last channel group of at most 32 channels with the paired packing: its runs take two steps (taps 0 + 1, tap 2)
-    const bool pair = p.wgt4p != nullptr && (p.C8 & 7) != 0 && (p.C8 & 7) <= 4;
+    constexpr bool RT = TAIL < 0;
+    const bool pair = RT ? ((PROF & 64) == 0 && p.wgt4p != nullptr && (p.C8 & 7) != 0 && (p.C8 & 7) <= 4) : TAIL == 2;
     const int steps_per_tile = pair ? 9 * G - 3 : 9 * G;
     const int total_runs = my_tiles * runs_per_tile;
 
@@ -266,17 +278,18 @@ conv_v5_kernel(const ConvArgs p) {
     };
     auto set_a_eff_one = [&](int buf, int r, int s, int i, unsigned a_s) __attribute__((always_inline)) {
         const unsigned a = a_s + (unsigned)(buf * A_BUF + i * 2048);
-        a_eff[i] = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
+        if constexpr ((PROF & 32) != 0) a_eff[i] = a;
+        else a_eff[i] = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
         // (pinned here, in the first half of a step: left alone the compiler sinks the select into the second half, next
         // to the read that uses it -- the half that also issues the DMA pieces and has no instruction slot to spare)
         asm volatile("" : "+v"(a_eff[i]));
     };
     auto read_x = [&](int i, int kk) -> frag8_t {
-        return *(const __attribute__((address_space(3))) frag8_t*)(smem + (a_eff[i] ^ (unsigned)(kk * 64)));
+        return *(const __attribute__((address_space(3))) frag8_t*)lds_at(a_eff[i] ^ (unsigned)(kk * 64));
     };
     auto read_w = [&](int stage, int kk, int j) -> frag8_t {
-        return *(const __attribute__((address_space(3))) frag8_t*)(smem + stage * B_BYTES + j * 2048 +
-                                                                 (b_frag_base ^ (kk * 64)));
+        return *(const __attribute__((address_space(3))) frag8_t*)lds_at((unsigned)(stage * B_BYTES + j * 2048) +
+                                                                        (unsigned)(b_frag_base ^ (kk * 64)));
     };
 
     f32x4 acc[FM][FN];
@@ -504,21 +517,24 @@ conv_v5_kernel(const ConvArgs p) {
     if constexpr ((PROF & 1) != 0) t_prev = __builtin_amdgcn_s_memtime();
 #define MDHIP_FENCE() __builtin_amdgcn_sched_barrier(0)
     // a half-full last channel group (C_in mod 64 <= 32) has nothing in k 32..63: its second-half MFMAs are skipped
-    const bool tail_short = (p.C8 & 7) != 0 && (p.C8 & 7) <= 4;
+    const bool tail_short = RT ? ((PROF & 64) == 0 && (p.C8 & 7) != 0 && (p.C8 & 7) <= 4) : TAIL >= 1;
     // DMA slots behind the MFMA chunks of a second half: the weight pieces of step + 2, then this step's share of the NEXT
     // run's pieces -- the first A_H0 in step 0 and the rest in step 1, or all of them in step 0 of a paired run
     constexpr int DMA_MAX = B_PER + A_PER, DMA_PER_G = (DMA_MAX + FN - 1) / FN;
     for (int run = 0; run < total_runs; ++run) {
         const bool last_cg = c_cg == G - 1;
-        const bool pair_run = pair && last_cg;                 // this run: taps 0 + 1 in one step, then tap 2
         const bool tile_end = c_r == 2 && last_cg;
         const int n_r = c_r == 2 ? 0 : c_r + 1;
+        // (TAIL == 0: both are compile-time false and every test below folds away.  Two copies of the steps -- one for the
+        // full groups, one for the last -- were tried for TAIL 1 / 2: 320+ spilled registers in the 8-wave tiles)
+        const bool pair_run = TAIL == 0 ? false : (pair && last_cg);           // this run: taps 0 + 1 in one step, then tap 2
+        const bool short_run = TAIL == 0 ? false : (tail_short && last_cg);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (s == 1 && pair_run) continue;
             const int cur = step & 1;
             // no MFMAs on k 32..63: a half-full last group's step, unless it carries the second tap of a pair there
-            const bool skip_y = tail_short && last_cg && !(pair_run && s == 0);
+            const bool skip_y = short_run && !(pair_run && s == 0);
             // the step being prefetched: the next tap of this run, or the first tap of the next run
             const int ns = s == 2 ? 0 : ((s == 0 && pair_run) ? 2 : s + 1);
             const int nbuf = s == 2 ? pa ^ 1 : pa;
@@ -532,7 +548,7 @@ conv_v5_kernel(const ConvArgs p) {
             auto read_y = [&](int i) __attribute__((always_inline)) -> frag8_t {
                 if (s == 0 && pair_run) {
                     const unsigned a = ((vmask[i] >> (c_r * 3 + 1)) & 1u) ? a_pair + (unsigned)(i * 2048) : z_addr;
-                    return *(const __attribute__((address_space(3))) frag8_t*)(smem + a);
+                    return *(const __attribute__((address_space(3))) frag8_t*)lds_at(a);
                 }
                 return read_x(i, 1);
             };
@@ -640,7 +656,11 @@ conv_v5_kernel(const ConvArgs p) {
     X(13, 320, 160, 4, 2, 6) \
     X(14, 320, 160, 4, 2, 22) \
     X(15, 320, 160, 4, 2, 2) \
-    X(16, 320, 160, 4, 2, 3)
+    X(16, 320, 160, 4, 2, 3) \
+    X(17, 320, 160, 4, 2, 32) \
+    X(18, 320, 160, 4, 2, 64) \
+    X(19, 320, 160, 4, 2, 96) \
+    X(20, 320, 160, 4, 2, 118)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
@@ -649,7 +669,7 @@ static const ConvCfg g_cfgs5[] = {
     MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
 #undef X
 };
-constexpr int kNumProf5 = 9;
+constexpr int kNumProf5 = 13;
 
 // ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp and the C = 80
 // strip kernel of conv_v5c.cpp (same K order, same results), then the developer variants
@@ -671,7 +691,19 @@ hipError_t conv5_init() {
     if (e == hipSuccess)                                                                       \
         e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof>,                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs5[id].lds_bytes);
-    MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
+    MDHIP_CONV5_PROF(X)
+#undef X
+#define X(id, bm, bn, wm, wn, prof)                                                              \
+    if (e == hipSuccess)                                                                       \
+        e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0>,             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs5[id].lds_bytes); \
+    if (e == hipSuccess)                                                                       \
+        e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 1>,             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs5[id].lds_bytes); \
+    if (e == hipSuccess)                                                                       \
+        e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 2>,             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs5[id].lds_bytes);
+    MDHIP_CONV5_CFGS(X)
 #undef X
     return e;
 }
@@ -708,12 +740,23 @@ hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     p.tiles_per_xcd = (p.tiles_m + 7) / 8;
     p.m_streams = std::max(1, std::min(p.tiles_per_xcd, (32 * c.blocks_per_cu) / p.tiles_n));
     const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
+    // the last channel group (see TAIL): at most half full -> its k 32..63 MFMAs are skipped; with the paired packing two taps a step
+    const bool tail_short = (a.C8 & 7) != 0 && (a.C8 & 7) <= 4;
+    const int tail = !tail_short ? 0 : (a.wgt4p != nullptr ? 2 : 1);
     switch (cfg) {
+#define X(id, bm, bn, wm, wn, prof)                                                               \
+    case id:                                                                                    \
+        if (tail == 0) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 0>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        else if (tail == 1) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 1>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        else hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 2>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        break;
+        MDHIP_CONV5_CFGS(X)
+#undef X
 #define X(id, bm, bn, wm, wn, prof)                                                               \
     case id:                                                                                    \
         hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         break;
-        MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
+        MDHIP_CONV5_PROF(X)
 #undef X
     }
     return hipGetLastError();
