@@ -66,6 +66,9 @@ constexpr int v5_blocks_per_cu(int bm, int bn, int nw) {
     if (b > 8 / nw) b = 8 / nw;          // two waves per SIMD (256 registers each)
     return b < 1 ? 1 : b;
 }
+constexpr bool v5_is_lean(int bm, int bn, int wm, int wn) { return bm / wm == 80 && bn / wn == 80; }
+// aligned mode (conv_v5_kernel AL): zero rows at ZERO_OFF + i * 2048, i = 1..4, behind the zero row / bias area
+constexpr int v5_al_extra_lds = 4 * 2048;
 constexpr int v5_waves_per_simd(int bm, int bn, int nw) {
     int w = v5_blocks_per_cu(bm, bn, nw) * nw / 4;
     return w < 1 ? 1 : w;
@@ -83,7 +86,12 @@ constexpr int v5_waves_per_simd(int bm, int bn, int nw) {
 // tests cost 4 % on the 320-channel layers, which have no tail at all): 0 = every group is full (or more than half full),
 // 1 = a last group of <= 32 channels (its k 32..63 MFMAs are skipped), 2 = that group with paired taps,
 // -1 = decided at run time (developer variants)
-template <int BM, int BN, int WM, int WN, int PROF = 0, int TAIL = -1>
+// AL ("aligned", 8-wave tiles only): the 80 pixels of a wave lie inside ONE image row (W a multiple of 80).  Tap validity
+// is then a handful of per-wave scalars -- top / bottom row, first / last pixel of the row in fragment 0 / 4 -- instead of a
+// 9-bit mask per lane and fragment: one address register for fragments 1..3 (fragment i at the immediate offset i * 2048, a
+// row of zeros at each of those offsets for a wave whose tap falls above / below the image), two for the edge fragments;
+// 5-6 VALU instructions a step instead of ~36 (a select per fragment, the shift arithmetic, the k-half XOR per fragment).
+template <int BM, int BN, int WM, int WN, int PROF = 0, int TAIL = -1, bool AL = false>
 __global__ void __launch_bounds__(WM * WN * 64, v5_waves_per_simd(BM, BN, WM * WN))
 conv_v5_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -135,7 +143,13 @@ conv_v5_kernel(const ConvArgs p) {
     // workgroup's BN output channels, staged once: the epilogue of every tile reads its 4 channels per fragment column
     // with one ds_read_b128 instead of a scalar load + wait per column (5 dependent round trips per tile)
     static_assert(BN * 4 + 256 <= v5_zero_bytes(BN), "bias staging area");
+    static_assert(!AL || (TM == 80 && TN == 80 && BN * 4 + 256 <= 2048), "aligned mode: 80x80 wave tiles");
     if (tid < 16) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+    if constexpr (AL) {
+        // (aligned mode: 256 bytes of zeros at ZERO_OFF + i * 2048 for every fragment row i; v5_al_extra_lds)
+        for (int c = tid; c < (FM - 1) * 16; c += NW * 64)
+            *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + (c / 16 + 1) * 2048 + (c % 16) * 16) = make_uint4(0, 0, 0, 0);
+    }
     for (int c = tid; c < BN; c += NW * 64)
         *(__attribute__((address_space(3))) float*)(smem + ZERO_OFF + 256 + c * 4) = (n0 + c < p.n_rows) ? p.bias[n0 + c] : 0.f;
 
@@ -256,8 +270,43 @@ conv_v5_kernel(const ConvArgs p) {
     };
     const unsigned z_addr = (unsigned)(ZERO_OFF + c0 * 16);
     const int b_frag_base = B_OFF + (wn * TN + (lane & 15)) * 128 + ((c0 ^ (lane & 7)) << 4);
-    uint32_t vmask[FM];                            // tap-validity bits of this lane's FM pixels (tile being read)
-    unsigned a_eff[FM];                            // LDS address of the fragments of the step being read
+    uint32_t vmask[AL ? 1 : FM];                   // tap-validity bits of this lane's FM pixels (tile being read)
+    unsigned a_eff[AL ? 1 : FM];                   // LDS address of the fragments of the step being read
+    // aligned mode: X = k 0..31 addresses of the step being read next (fragments 1..3 / fragment 0 / fragment 4, each + i * 2048),
+    // Y = the k 32..63 addresses of the step being computed
+    [[maybe_unused]] unsigned al_bx = 0, al_e0 = 0, al_e4 = 0, al_by = 0, al_f0 = 0, al_f4 = 0;
+    [[maybe_unused]] int wflags = 16;              // of this wave in the tile being read: 1 top row, 2 bottom row, 4 starts a row, 8 ends one, 16 outside the batch
+    [[maybe_unused]] unsigned al_sh[3] = {0, 0, 0};
+    if constexpr (AL) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) al_sh[s] = a_shift(lane, s);
+    }
+    [[maybe_unused]] const bool lane_p0 = (lane & 15) == 0, lane_p15 = (lane & 15) == 15;
+    auto wave_flags = [&](int t) __attribute__((always_inline)) {
+        const int mw = t * BM + wm * TM;           // (scalar: the wave's first pixel)
+        int f = 16;
+        if (mw < p.M) {
+            const int b = mw / p.HoWo;
+            const int rem = mw - b * p.HoWo;
+            const int y = rem / p.W;
+            const int x = rem - y * p.W;
+            f = (y == 0 ? 1 : 0) | (y == p.H - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x + TM == p.W ? 8 : 0);
+        }
+        wflags = __builtin_amdgcn_readfirstlane(f);
+    };
+    // the k 0..31 addresses of step (buf, r, s) from the wave's flags: everything reads zeros when the kernel row falls above /
+    // below the image (or the wave lies behind the batch); lane 0 of fragment 0 / lane 15 of fragment 4 when the tap falls
+    // left / right of it
+    auto al_x_addresses = [&](int buf, int r, int s) __attribute__((always_inline)) {
+        const unsigned a = (s == 0 ? al_sh[0] : (s == 1 ? al_sh[1] : al_sh[2])) + (unsigned)(buf * A_BUF);
+        // (bit arithmetic, not || chains: those become a branch per term)
+        const int kill = wflags & (16 | (r == 0 ? 1 : 0) | (r == 2 ? 2 : 0));
+        al_bx = kill != 0 ? z_addr : a;
+        const int edge0 = wflags & (s == 0 ? 4 : 0), edge4 = wflags & (s == 2 ? 8 : 0);
+        al_e0 = (edge0 != 0 && lane_p0) ? z_addr : al_bx;
+        al_e4 = (edge4 != 0 && lane_p15) ? z_addr : al_bx;
+        asm volatile("" : "+v"(al_bx), "+v"(al_e0), "+v"(al_e4));
+    };
     auto tile_masks = [&](int t) __attribute__((always_inline)) {
         const int mb = t * BM + wm * TM + (lane & 15);
 #pragma unroll
@@ -285,7 +334,10 @@ conv_v5_kernel(const ConvArgs p) {
         asm volatile("" : "+v"(a_eff[i]));
     };
     auto read_x = [&](int i, int kk) -> frag8_t {
-        return *(const __attribute__((address_space(3))) frag8_t*)lds_at(a_eff[i] ^ (unsigned)(kk * 64));
+        if constexpr (AL) {
+            const unsigned a = kk == 0 ? (i == 0 ? al_e0 : (i == FM - 1 ? al_e4 : al_bx)) : (i == 0 ? al_f0 : (i == FM - 1 ? al_f4 : al_by));
+            return *(const __attribute__((address_space(3))) frag8_t*)lds_at(a + (unsigned)(i * 2048));
+        } else return *(const __attribute__((address_space(3))) frag8_t*)lds_at(a_eff[i] ^ (unsigned)(kk * 64));
     };
     auto read_w = [&](int stage, int kk, int j) -> frag8_t {
         return *(const __attribute__((address_space(3))) frag8_t*)lds_at((unsigned)(stage * B_BYTES + j * 2048) +
@@ -496,9 +548,14 @@ conv_v5_kernel(const ConvArgs p) {
     __builtin_amdgcn_s_barrier();
 
     frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
-    tile_masks(first_tile);
+    if constexpr (AL) {
+        wave_flags(first_tile);
+        al_x_addresses(0, 0, 0);
+    } else {
+        tile_masks(first_tile);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) set_a_eff_one(0, 0, 0, i, a_shift_now(0));
+        for (int i = 0; i < FM; ++i) set_a_eff_one(0, 0, 0, i, a_shift_now(0));
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) xa[i] = read_x(i, 0);
 #pragma unroll
@@ -539,14 +596,30 @@ conv_v5_kernel(const ConvArgs p) {
             const int ns = s == 2 ? 0 : ((s == 0 && pair_run) ? 2 : s + 1);
             const int nbuf = s == 2 ? pa ^ 1 : pa;
             const int nr = s == 2 ? n_r : c_r;
-            if (s == 2 && tile_end) tile_masks(c_tile + tile_step);       // (masks of a tile past the stream's end are never used)
-            const unsigned a_next = a_shift_now(ns);
-            // (paired step: the k 32..63 half is tap 1 of this kernel row -- the fragments one pixel on, k 0..31)
-            const unsigned a_pair = (s == 0 && pair_run) ? a_shift_now(1) + (unsigned)(pa * A_BUF) : 0u;
+            unsigned a_next = 0, a_pair = 0;
+            if constexpr (AL) {
+                // the k 32..63 addresses of THIS step: the other half of the same rows -- or, first step of a paired run, tap 1
+                // of this kernel row: k 0..31 one pixel on, no pixel of it left or right of the image
+                al_by = al_bx ^ 64u;
+                al_f0 = al_e0 ^ 64u;
+                al_f4 = al_e4 ^ 64u;
+                if (s == 0 && pair_run) {
+                    const int kill = wflags & (16 | (c_r == 0 ? 1 : 0) | (c_r == 2 ? 2 : 0));
+                    al_by = al_f0 = al_f4 = kill != 0 ? z_addr : al_sh[1] + (unsigned)(pa * A_BUF);
+                }
+                if (s == 2 && tile_end) wave_flags(c_tile + tile_step);   // (flags of a tile past the stream's end are never used)
+                al_x_addresses(nbuf, nr, ns);
+            } else {
+                if (s == 2 && tile_end) tile_masks(c_tile + tile_step);   // (masks of a tile past the stream's end are never used)
+                a_next = a_shift_now(ns);
+                // (paired step: the k 32..63 half is tap 1 of this kernel row -- the fragments one pixel on, k 0..31)
+                a_pair = (s == 0 && pair_run) ? a_shift_now(1) + (unsigned)(pa * A_BUF) : 0u;
+            }
             // ---- first half: k 0..31 of this step, while its k 32..63 fragments are read and the
             //      fragment addresses of the next step are selected; MFMA chunk g = fragment column g ----
             auto read_y = [&](int i) __attribute__((always_inline)) -> frag8_t {
-                if (s == 0 && pair_run) {
+                if constexpr (AL) return read_x(i, 1);
+                else if (s == 0 && pair_run) {
                     const unsigned a = ((vmask[i] >> (c_r * 3 + 1)) & 1u) ? a_pair + (unsigned)(i * 2048) : z_addr;
                     return *(const __attribute__((address_space(3))) frag8_t*)lds_at(a);
                 }
@@ -558,10 +631,10 @@ conv_v5_kernel(const ConvArgs p) {
                 // spare fragment, read first): 6 weight fragments live instead of 10
                 if constexpr (LEAN) wb[(g + FN - 1) % FN] = read_w(cur, 1, (g + FN - 1) % FN);
                 else wb[g] = read_w(cur, 1, g);
-                if (g < FM) { xb[g] = read_y(g); set_a_eff_one(nbuf, nr, ns, g, a_next); }
+                if (g < FM) { xb[g] = read_y(g); if constexpr (!AL) set_a_eff_one(nbuf, nr, ns, g, a_next); }
                 if (g == FN - 1) {
 #pragma unroll
-                    for (int i = FN; i < FM; ++i) { xb[i] = read_y(i); set_a_eff_one(nbuf, nr, ns, i, a_next); }
+                    for (int i = FN; i < FM; ++i) { xb[i] = read_y(i); if constexpr (!AL) set_a_eff_one(nbuf, nr, ns, i, a_next); }
                 }
                 MDHIP_FENCE();
 #pragma unroll
@@ -694,6 +767,12 @@ hipError_t conv5_init() {
     MDHIP_CONV5_PROF(X)
 #undef X
 #define X(id, bm, bn, wm, wn, prof)                                                              \
+    if constexpr ((bm) * (bn) == 320 * 160 && (wm) * (wn) == 8) {                                   \
+        const int al_lds = (int)g_cfgs5[id].lds_bytes + v5_al_extra_lds;                          \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 1, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 2, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
+    }                                                                                          \
     if (e == hipSuccess)                                                                       \
         e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0>,             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs5[id].lds_bytes); \
@@ -743,9 +822,18 @@ hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     // the last channel group (see TAIL): at most half full -> its k 32..63 MFMAs are skipped; with the paired packing two taps a step
     const bool tail_short = (a.C8 & 7) != 0 && (a.C8 & 7) <= 4;
     const int tail = !tail_short ? 0 : (a.wgt4p != nullptr ? 2 : 1);
+    // the 8-wave tiles' aligned mode (conv_v5_kernel AL): a wave's 80 pixels inside one image row; same results
+    const bool aligned = (a.W % 80) == 0 && a.dev_param != 77;
     switch (cfg) {
 #define X(id, bm, bn, wm, wn, prof)                                                               \
     case id:                                                                                    \
+        if (v5_is_lean(bm, bn, wm, wn) && aligned) {                                            \
+            const size_t al_lds = c.lds_bytes + v5_al_extra_lds;                                  \
+            if (tail == 0) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), al_lds, s, p); \
+            else if (tail == 1) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 1, v5_is_lean(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), al_lds, s, p); \
+            else hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 2, v5_is_lean(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), al_lds, s, p); \
+            break;                                                                              \
+        }                                                                                       \
         if (tail == 0) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 0>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         else if (tail == 1) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 1>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         else hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 2>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \

@@ -85,6 +85,8 @@ conv_v5s_kernel(const ConvArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lds_char* const smem = (lds_char*)smem_generic;
+    // (fragment reads address LDS by number, conv_v5.cpp: the dynamic block must start at byte 0)
+    if ((unsigned)(uintptr_t)smem != 0u) __builtin_trap();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -208,12 +210,12 @@ conv_v5s_kernel(const ConvArgs p) {
         for (int i = 0; i < FM; ++i) {
             const unsigned a = a_sh[s] + (unsigned)(stage * STAGE + i * 2048);
             const unsigned e = ((vmask[i] >> (r * 3 + s)) & 1u) ? a : z_addr;
-            fx[hs][i] = *(const __attribute__((address_space(3))) frag8_t*)(smem + (e ^ (unsigned)(kk * 64)));
+            fx[hs][i] = *(const __attribute__((address_space(3))) frag8_t*)(const lds_char*)(e ^ (unsigned)(kk * 64));
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-            fw[hs][j] = *(const __attribute__((address_space(3))) frag8_t*)(smem + stage * STAGE + A_PAD + s * B_BYTES +
-                                                                          j * 2048 + (b_frag_base ^ (kk * 64)));
+            fw[hs][j] = *(const __attribute__((address_space(3))) frag8_t*)(const lds_char*)((unsigned)(stage * STAGE + A_PAD + s * B_BYTES + j * 2048) +
+                                                                                           (unsigned)(b_frag_base ^ (kk * 64)));
     };
 
     f32x4 acc[FM][FN];

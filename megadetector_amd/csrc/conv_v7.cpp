@@ -76,6 +76,8 @@ conv_v7_kernel(const ConvArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lds_char* const smem = (lds_char*)smem_generic;
+    // (fragment reads address LDS by number, conv_v5.cpp: the dynamic block must start at byte 0)
+    if ((unsigned)(uintptr_t)smem != 0u) __builtin_trap();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -230,11 +232,11 @@ conv_v7_kernel(const ConvArgs p) {
         asm volatile("" : "+v"(a_eff[i]));
     };
     auto read_x = [&](int i, int kk) -> frag8_t {
-        return *(const __attribute__((address_space(3))) frag8_t*)(smem + (a_eff[i] ^ (unsigned)(kk * 64)));
+        return *(const __attribute__((address_space(3))) frag8_t*)(const lds_char*)(a_eff[i] ^ (unsigned)(kk * 64));
     };
     auto read_w = [&](int stage, int kk, int j) -> frag8_t {
-        return *(const __attribute__((address_space(3))) frag8_t*)(smem + stage * B_BYTES + j * 2048 +
-                                                                 (b_frag_base ^ (kk * 64)));
+        return *(const __attribute__((address_space(3))) frag8_t*)(const lds_char*)((unsigned)(stage * B_BYTES + j * 2048) +
+                                                                                  (unsigned)(b_frag_base ^ (kk * 64)));
     };
 
     f32x4 acc[FM][FN];
