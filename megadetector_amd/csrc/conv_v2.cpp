@@ -67,8 +67,9 @@ constexpr int v2_waves_per_simd(int bm, int bn, int nw) {
 // wave and written to p.dbg); used by tools/convbench.cpp, never by the product path
 // UP = the variant that reads the first K slabs of a 1x1 conv from a low-resolution tensor (nearest-neighbour upsample in
 // place, ConvArgs::in_up); its own instantiation so that the loader of every other launch stays as it was
-// PW = the instantiation for 1x1 / stride 1 / unpadded convs (tile set-up without divisions, see init_tile)
-template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false, bool PW = false>
+// PW = the instantiations for 1x1 / stride 1 / unpadded convs (tile set-up without divisions, see init_tile): 1 = the channel
+// count is a multiple of 64, 2 = it is not (the last K slab's chunks past the last channel are masked, see advance)
+template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false, int PW = 0>
 __global__ void __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BM, BN, WM * WN))
 conv_v2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -221,9 +222,15 @@ conv_v2_kernel(const ConvArgs p) {
                 // wider buffer, the neighbouring tensor's) against zero weights -- 0 * Inf / NaN would poison every output
                 // channel of the pixel.  Those lanes read zeros through the range check instead; init_tile restores
                 // the offsets with the next tile.
-                if (l_kt == KT - 1 && pw_tail_bad) {
+                // (the scalar test first: layers whose channel count is a multiple of 64 -- most -- branch over the block;
+                // as one per-lane condition it cost a dozen VALU instructions in every step of every layer)
+                // (its own instantiation: as a run-time test it cost a dozen VALU instructions in every step of every layer,
+                // whichever way it was written -- the compiler folds the scalar and the per-lane condition into one exec mask)
+                if constexpr (PW == 2) {
+                    if (l_kt == KT - 1 && pw_tail_bad) {
 #pragma unroll
-                    for (int i = 0; i < A_PER; ++i) a_off[i] = kOOB;
+                        for (int i = 0; i < A_PER; ++i) a_off[i] = kOOB;
+                    }
                 }
             }
             c8 += 8;
@@ -619,7 +626,10 @@ hipError_t conv2_init() {
         e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn>,                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes); \
     if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, true>,          \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, 1>,             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes); \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, 2>,             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
     MDHIP_CONV2_CFGS(X)
 #undef X
@@ -663,7 +673,8 @@ hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     switch (cfg) {
 #define X(id, bm, bn, wm, wn)                                                                        \
     case id:                                                                                       \
-        if (pw) hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, true>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        if (pw && (a.C8 & 7) == 0) hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, 1>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        else if (pw) hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, 2>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         else hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         break;
         MDHIP_CONV2_CFGS(X)
