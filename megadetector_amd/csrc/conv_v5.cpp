@@ -516,6 +516,8 @@ conv_v5_kernel(const ConvArgs p) {
     // The others take the activation flag at run time (std::false_type = "ask p.act").
     auto epilogue = [&](int tile_m) __attribute__((always_inline)) {
         if constexpr (LEAN) {
+            // (s_setprio 2 on the first four waves for the epilogue -- so that one wave of a SIMD computes while the other waits
+            // for the memory path -- was measured: no difference on any layer, profiles/r4_convbench_epilogue_prio.txt)
             if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::true_type{});
             else epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::true_type{});
         } else {

@@ -56,12 +56,18 @@ constexpr int kSub7 = kBM7 * 128;                                   // one sub-b
 constexpr int kStage7 = kBN7 * 128;                                 // one weight stage
 constexpr int kZero7 = 1024;                                        // the row of zeros (256 bytes) + the staged bias
 constexpr int kLds7 = 2 * kSub7 + 2 * kStage7 + kZero7;             // 123 904 bytes: one workgroup per CU
+constexpr int kAlExtra7 = 4 * 2048;                                 // aligned mode: zero rows at ZERO_OFF + i * 2048, i = 1..4
 
 }  // namespace
 
 #define MDHIP_DMA16(rsrc, lptr, voff, soff) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr), 16, (voff), (soff), 0, 0)
 
+// TAIL: 0 = the channel count is a multiple of 64 (no partly full last group: its tests are compiled out), 1 = it is not.
+// AL: a wave's 80 output pixels lie inside one output row (Wo a multiple of 80): tap validity from three per-wave flags --
+// inside the batch, top row, starts a row -- one address register for fragments 1..4 at the immediate offsets i * 2048 (a
+// row of zeros at each of those offsets), one for fragment 0, whose lane 0 may fall left of the image (conv_v5.cpp, AL).
+template <int TAIL, bool AL>
 __global__ void __launch_bounds__(kNW7 * 64, 2)
 conv_v7_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -101,6 +107,10 @@ conv_v7_kernel(const ConvArgs p) {
     const int total_runs = my_tiles * runs_per_tile;
 
     if (tid < 16) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+    if constexpr (AL) {
+        for (int c = tid; c < (FM - 1) * 16; c += NW * 64)
+            *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + (c / 16 + 1) * 2048 + (c % 16) * 16) = make_uint4(0, 0, 0, 0);
+    }
     for (int c = tid; c < BN; c += NW * 64)
         *(__attribute__((address_space(3))) float*)(smem + ZERO_OFF + 256 + c * 4) = p.bias[n0 + c];
 
@@ -171,7 +181,7 @@ conv_v7_kernel(const ConvArgs p) {
         const unsigned base = (unsigned)(lg_px0 + lg_r * p.W) * (unsigned)p.ld_in * 2u + (unsigned)(lg_cg * 128);
         g.so_e = ok ? base : kOOB;
         g.so_o = ok ? base + (unsigned)p.ld_in * 2u : kOOB;
-        g.tail = lg_cg == G - 1 && (p.C8 & 7) != 0;
+        g.tail = TAIL != 0 && lg_cg == G - 1 && (p.C8 & 7) != 0;
         return g;
     };
     auto run_next = [&]() __attribute__((always_inline)) {
@@ -188,7 +198,9 @@ conv_v7_kernel(const ConvArgs p) {
         unsigned so = so_base + (unsigned)i * q_stride;
         asm volatile("" : "+s"(so));
         unsigned voff = q_off + so;                                       // (so_base = kOOB: far outside the descriptor)
-        if (tail) voff = tail_bad ? kOOB : voff;                          // (wave-uniform branch: last group only)
+        if constexpr (TAIL != 0) {
+            if (tail) voff = tail_bad ? kOOB : voff;                      // (wave-uniform branch: last group only)
+        }
         MDHIP_DMA16(a_rsrc, smem + sub + (wave * A_PER + i) * 1024, voff, 0);
     };
 
@@ -206,8 +218,38 @@ conv_v7_kernel(const ConvArgs p) {
     };
     const unsigned z_addr = (unsigned)(ZERO_OFF + c0 * 16);
     const int b_frag_base = B_OFF + (wn * TN + (lane & 15)) * 128 + ((c0 ^ (lane & 7)) << 4);
-    uint32_t vmask[FM];                            // per pixel: bit 0 = inside the batch, bit 1 = oy > 0, bit 2 = ox > 0
-    unsigned a_eff[FM];                            // LDS address of the fragments of the step being read
+    uint32_t vmask[AL ? 1 : FM];                   // per pixel: bit 0 = inside the batch, bit 1 = oy > 0, bit 2 = ox > 0
+    unsigned a_eff[AL ? 1 : FM];                   // LDS address of the fragments of the step being read
+    // aligned mode: k 0..31 addresses of the step read next (fragments 1..4 / fragment 0, each + i * 2048) and the k 32..63
+    // addresses of the step being computed; the wave's flags in the tile being read: 1 inside the batch, 2 oy > 0, 4 ox > 0
+    [[maybe_unused]] unsigned al_bx = 0, al_e0 = 0, al_by = 0, al_f0 = 0;
+    [[maybe_unused]] int wflags = 0;
+    [[maybe_unused]] unsigned al_sh[2] = {0, 0};   // shift -1 (tap 0), shift 0
+    if constexpr (AL) {
+        al_sh[0] = a_shift(lane, -1);
+        al_sh[1] = a_shift(lane, 0);
+    }
+    [[maybe_unused]] const bool lane_p0 = (lane & 15) == 0;
+    auto wave_flags = [&](int t) __attribute__((always_inline)) {
+        const int mw = t * BM + wm * TM;           // (scalar: the wave's first output pixel)
+        int f = 0;
+        if (mw < p.M) {
+            const int b = mw / p.HoWo;
+            const int rem = mw - b * p.HoWo;
+            const int y = rem / p.Wo;
+            const int x = rem - y * p.Wo;
+            f = 1 | (y > 0 ? 2 : 0) | (x > 0 ? 4 : 0);
+        }
+        wflags = __builtin_amdgcn_readfirstlane(f);
+    };
+    auto al_x_addresses = [&](int r, int st) __attribute__((always_inline)) {
+        const unsigned a = (st == 0 ? al_sh[0] : al_sh[1]) + (unsigned)(st == 2 ? E_OFF : O_OFF);
+        const int need = 1 | (r == 0 ? 2 : 0);
+        al_bx = (wflags & need) == need ? a : z_addr;
+        const int edge = st == 0 ? (~wflags & 4) : 0;                 // tap 0 of a wave that starts a row: lane 0 of fragment 0
+        al_e0 = (edge != 0 && lane_p0) ? z_addr : al_bx;
+        asm volatile("" : "+v"(al_bx), "+v"(al_e0));
+    };
     auto tile_masks = [&](int t) __attribute__((always_inline)) {
         const int mb = t * BM + wm * TM + (lane & 15);
 #pragma unroll
@@ -232,7 +274,10 @@ conv_v7_kernel(const ConvArgs p) {
         asm volatile("" : "+v"(a_eff[i]));
     };
     auto read_x = [&](int i, int kk) -> frag8_t {
-        return *(const __attribute__((address_space(3))) frag8_t*)(const lds_char*)(a_eff[i] ^ (unsigned)(kk * 64));
+        if constexpr (AL) {
+            const unsigned a = kk == 0 ? (i == 0 ? al_e0 : al_bx) : (i == 0 ? al_f0 : al_by);
+            return *(const __attribute__((address_space(3))) frag8_t*)(const lds_char*)(a + (unsigned)(i * 2048));
+        } else return *(const __attribute__((address_space(3))) frag8_t*)(const lds_char*)(a_eff[i] ^ (unsigned)(kk * 64));
     };
     auto read_w = [&](int stage, int kk, int j) -> frag8_t {
         return *(const __attribute__((address_space(3))) frag8_t*)(const lds_char*)((unsigned)(stage * B_BYTES + j * 2048) +
@@ -322,8 +367,11 @@ conv_v7_kernel(const ConvArgs p) {
     __builtin_amdgcn_s_barrier();
 
     frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
-    tile_masks(first_tile);
-    {
+    if constexpr (AL) {
+        wave_flags(first_tile);
+        al_x_addresses(0, 0);
+    } else {
+        tile_masks(first_tile);
         const unsigned a0 = a_shift_now(-1) + (unsigned)O_OFF;
 #pragma unroll
         for (int i = 0; i < FM; ++i) set_a_eff_one(0, 0, i, a0);
@@ -336,7 +384,7 @@ conv_v7_kernel(const ConvArgs p) {
     int c_r = 0, c_cg = 0, c_tile = first_tile, step = 0;
 #define MDHIP_FENCE() __builtin_amdgcn_sched_barrier(0)
     // a last channel group of at most 32 channels has nothing in k 32..63: its second-half MFMAs are skipped
-    const bool tail_short = (p.C8 & 7) != 0 && (p.C8 & 7) <= 4;
+    const bool tail_short = TAIL != 0 && (p.C8 & 7) != 0 && (p.C8 & 7) <= 4;
     constexpr int DMA_MAX = B_PER + A_PER, DMA_PER_G = (DMA_MAX + FN - 1) / FN;
     for (int run = 0; run < total_runs; ++run) {
         const bool skip_y = tail_short && c_cg == G - 1;
@@ -348,8 +396,16 @@ conv_v7_kernel(const ConvArgs p) {
             // the step being prefetched: tap 2 / tap 1 of this kernel row, or tap 0 of the next run
             const int nst = st == 2 ? 0 : st + 1;
             const int nr = st == 2 ? n_r : c_r;
-            if (st == 2 && tile_end) tile_masks(c_tile + tile_step);       // (masks of a tile past the stream's end are never used)
-            const unsigned a_next = a_shift_now(nst == 0 ? -1 : 0) + (unsigned)(nst == 2 ? E_OFF : O_OFF);
+            unsigned a_next = 0;
+            if constexpr (AL) {
+                al_by = al_bx ^ 64u;                                       // the k 32..63 addresses of THIS step
+                al_f0 = al_e0 ^ 64u;
+                if (st == 2 && tile_end) wave_flags(c_tile + tile_step);   // (flags of a tile past the stream's end are never used)
+                al_x_addresses(nr, nst);
+            } else {
+                if (st == 2 && tile_end) tile_masks(c_tile + tile_step);   // (masks of a tile past the stream's end are never used)
+                a_next = a_shift_now(nst == 0 ? -1 : 0) + (unsigned)(nst == 2 ? E_OFF : O_OFF);
+            }
             // ---- first half: k 0..31 of this step, while its k 32..63 fragments are read and the fragment addresses
             //      of the next step are selected; MFMA chunk g = fragment column g ----
 #pragma unroll
@@ -357,7 +413,7 @@ conv_v7_kernel(const ConvArgs p) {
                 // (the weight fragment of the other k half goes into the registers the chunk before released)
                 wb[(g + FN - 1) % FN] = read_w(cur, 1, (g + FN - 1) % FN);
                 xb[g] = read_x(g, 1);
-                set_a_eff_one(nr, nst, g, a_next);
+                if constexpr (!AL) set_a_eff_one(nr, nst, g, a_next);
                 MDHIP_FENCE();
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
@@ -418,7 +474,11 @@ int conv7_num_cfgs() { return 1; }
 const ConvCfg& conv7_cfg(int) { return g_cfg7; }
 
 hipError_t conv7_init() {
-    return hipFuncSetAttribute((const void*)conv_v7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds7);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_v7_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds7);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v7_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds7);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v7_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds7 + kAlExtra7);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v7_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds7 + kAlExtra7);
+    return e;
 }
 
 bool conv7_supports(int cfg, const ConvArgs& a) {
@@ -442,7 +502,16 @@ hipError_t conv7_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     p.tiles_per_xcd = (p.tiles_m + 7) / 8;
     p.m_streams = std::max(1, std::min(p.tiles_per_xcd, 32 / p.tiles_n));
     const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
-    hipLaunchKernelGGL(conv_v7_kernel, grid, dim3(kNW7 * 64), kLds7, s, p);
+    // same results from every instantiation: what the last channel group looks like, and whether a wave's 80 output pixels lie
+    // inside one output row
+    const bool tail = (a.C8 & 7) != 0, aligned = (a.Wo % 80) == 0 && a.dev_param != 77;
+    if (aligned) {
+        if (tail) hipLaunchKernelGGL((conv_v7_kernel<1, true>), grid, dim3(kNW7 * 64), kLds7 + kAlExtra7, s, p);
+        else hipLaunchKernelGGL((conv_v7_kernel<0, true>), grid, dim3(kNW7 * 64), kLds7 + kAlExtra7, s, p);
+    } else {
+        if (tail) hipLaunchKernelGGL((conv_v7_kernel<1, false>), grid, dim3(kNW7 * 64), kLds7, s, p);
+        else hipLaunchKernelGGL((conv_v7_kernel<0, false>), grid, dim3(kNW7 * 64), kLds7, s, p);
+    }
     return hipGetLastError();
 }
 
