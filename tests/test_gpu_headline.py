@@ -572,3 +572,49 @@ def test_stride2_row_run_kernel_against_the_oracle_and_batch_invariant(dtype, mo
             np.testing.assert_array_equal(ctx.read_predictions(1)[0], pred[i])
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_aligned_mode_of_the_8_wave_tiles_is_bit_identical_to_the_general_tiles(dtype, monkeypatch):
+    """The 8-wave tiles of conv_v5.cpp / conv_v7.cpp run an "aligned" instantiation where a wave's 80 pixels lie inside one
+    image row (W a multiple of 80): tap validity from per-wave flags instead of per-lane masks, fragment addresses at
+    immediate offsets, rows of zeros for taps above / below the image; and their channel-tail handling is a compile-time
+    mode.  Same operands, same MFMA order: the x6 stack at 128x1280 (stride 8: 16x160 maps, 160 channels = paired tail;
+    stride 16: 8x80 maps, 320 channels = no tail; images of 2 / 8 tiles, top and bottom rows in every tile) must give the
+    SAME BITS as the general 128x160 two-workgroup tile of the same family, with the arena poisoned, for a batch and for
+    single images."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
+    n, hh, ww = 3, 128, 1280
+    imgs = PU.structured_images(n, hh, ww, seed=29)
+    monkeypatch.setenv('MDHIP_ARENA_POISON', '1')
+    ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+    try:
+        names = {ctx.conv_cfg_name(c): c for c in range(ctx.num_conv_cfgs())}
+        lean, general = names['v5:run320x160/4x2/0'], names['v5:run128x160/2x2/0']
+        ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+        ctx.forward(n, hh, ww)
+        convs = [o for o in ctx.op_infos() if o['kind'] == 0 and o['ntaps'] == 9 and o['stride'] == 1]
+        takers = [o for o in convs if ctx.op_supports_cfg(o['op'], lean) and ctx.op_supports_cfg(o['op'], general)]
+        aligned = [o for o in takers if (o['m'] // n) % 80 == 0 and o['layer'] in (4, 6, 23, 26)]
+        assert len(aligned) >= 20, [o['name'] for o in takers]            # the bottleneck 3x3s of layers 4 / 23 (160 channels) and 6 / 26 (320)
+        assert {o['k'] for o in aligned} >= {1440, 2880}
+        for o in takers:
+            ctx.set_op_cfg(o['op'], general)
+        ctx.forward(n, hh, ww)
+        ref = ctx.read_predictions(n).copy()
+        assert np.isfinite(ref).all()
+        for o in takers:
+            ctx.set_op_cfg(o['op'], lean)
+        ctx.forward(n, hh, ww)
+        ran = {ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['op'] in {t['op'] for t in takers}}
+        assert ran == {'v5:run320x160/4x2/0'}, ran
+        pred = ctx.read_predictions(n).copy()
+        np.testing.assert_array_equal(pred, ref)
+        for i in (0, 2):
+            ctx.preprocess([imgs[i]], _identity_geoms([imgs[i]]), hh, ww)
+            ctx.forward(1, hh, ww)
+            np.testing.assert_array_equal(ctx.read_predictions(1)[0], pred[i])
+    finally:
+        ctx.close()
