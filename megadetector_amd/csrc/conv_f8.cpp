@@ -165,7 +165,7 @@ conv_f8_kernel(const ConvArgs p) {
     };
     auto dma_run_piece = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
-        if (i * NW + wave >= A_PIECES) return;                                                  // wave-uniform
+        if (i * NW + NW - 1 >= A_PIECES && i * NW + wave >= A_PIECES) return;                   // wave-uniform (conv_v5.cpp)
         const bool ok = jj < p.C8 - lg_cg * 8;
         MDHIP_DMA16(a_rsrc, smem + buf * A_BUF + (i * NW + wave) * 1024, ok ? q_off[i] + lg_abs : kOOB, 0);
     };

@@ -225,7 +225,8 @@ conv_v5_kernel(const ConvArgs p) {
     // After the stream's last tile the loader re-reads runs of that tile into buffers nobody reads.
     auto dma_run_piece = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
-        if (i * NW + wave >= A_PIECES) return;                                                  // wave-uniform
+        // (tested only for the piece index where it can be true: the compiler does not know that wave < NW)
+        if (i * NW + NW - 1 >= A_PIECES && i * NW + wave >= A_PIECES) return;                   // wave-uniform
         if constexpr (LEAN) {
             unsigned so = lg_abs + (unsigned)i * q_stride;
             asm volatile("" : "+s"(so));
@@ -735,7 +736,10 @@ conv_v5_kernel(const ConvArgs p) {
     X(17, 320, 160, 4, 2, 32) \
     X(18, 320, 160, 4, 2, 64) \
     X(19, 320, 160, 4, 2, 96) \
-    X(20, 320, 160, 4, 2, 118)
+    X(20, 320, 160, 4, 2, 118) \
+    X(21, 320, 160, 4, 2, 66) \
+    X(22, 320, 160, 4, 2, 68) \
+    X(23, 320, 160, 4, 2, 70)
 
 static const ConvCfg g_cfgs5[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
@@ -744,7 +748,7 @@ static const ConvCfg g_cfgs5[] = {
     MDHIP_CONV5_CFGS(X) MDHIP_CONV5_PROF(X)
 #undef X
 };
-constexpr int kNumProf5 = 13;
+constexpr int kNumProf5 = 16;
 
 // ids: [0, kNumMain5) the configurations above, then the small-launch configurations of conv_v5s.cpp and the C = 80
 // strip kernel of conv_v5c.cpp (same K order, same results), then the developer variants

@@ -227,7 +227,87 @@ static void run_model(const char* label, const char* wsrc, const char* asrc, siz
            c / (best * 1e6), (double)(NB + NA) * 8 * 1024 / (c / steps));
 }
 
-int main() {
+// ---------------------------------------------------------------------------------------------------------------------
+// The epilogue's stores: what a 16-byte-per-lane buffer store costs by shape.  Every wave writes `rounds` groups of 16 pixels
+// x 80 channels (2560 bytes) of a [pixels][NCH] bf16 tensor, as the conv epilogue does: SHAPE 0 = fragment-shaped (lane =
+// (pixel, 16-byte chunk): 2 x b128 + 1 x b64 per group, each instruction touches 16 pixels x 64 bytes), SHAPE 1 = line-shaped
+// (the same bytes, but a wave instruction covers consecutive 16-byte chunks of consecutive pixels: 160 bytes per pixel -> 6.4
+// pixels per instruction, 2.5 instructions per group), SHAPE 2 = fully contiguous 1 KiB per instruction (what an N tile that
+// holds every channel of the tensor could write).  8 waves per CU, one workgroup per CU, every CU its own region.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int SHAPE>
+__global__ void __launch_bounds__(512) store_model(char* out, int nch, int rounds, unsigned long long* cyc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned row = (unsigned)nch * 2u;                         // bytes per pixel
+    const size_t region = (size_t)rounds * 64 * row;                  // a workgroup writes `rounds` groups of 4 x 16 pixels
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)blockIdx.x * region), 0, (int)region, 0x00020000);
+    const u32x4 d = {(unsigned)lane, 1u, 2u, (unsigned)wave};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned g0 = (unsigned)(r * 64 + wm * 16) * row + (unsigned)(wn * 160);     // the wave's 16 pixels x 80 channels
+        if (SHAPE == 0) {
+            const unsigned o = g0 + (unsigned)(lane & 15) * row + (unsigned)(lane >> 4) * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)(o + 64u), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rsrc, (int)(g0 + (unsigned)(lane & 15) * row + 128u + (unsigned)(lane >> 4) * 8u), 0, 0);
+        } else if (SHAPE == 1) {
+            // chunk c = 0..159 of the group: pixel c / 10, 16-byte chunk c % 10 of its 160 bytes
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned c = (unsigned)(k * 64 + lane);
+                const unsigned px = c / 10u, ch = c - px * 10u;
+                const unsigned o = c < 160u ? g0 + px * row + ch * 16u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)o, 0, 0);
+            }
+        } else {
+            // 2560 contiguous bytes per wave and group (as if the tensor had exactly this tile's channels)
+            const unsigned g1 = (unsigned)((r * 8 + wave) * 2560);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned c = (unsigned)(k * 64 + lane);
+                __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)(c < 160u ? g1 + c * 16u : 0x80000000u), 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (cyc && threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+#endif
+}
+
+template <int SHAPE>
+static void run_store(const char* label, char* out, int nch, int blocks, unsigned long long* cyc) {
+    const int rounds = 180;                       // 180 x 64 pixels x 640 bytes x 256 workgroups = 1.9 GB: inside the 2 GiB buffer
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((store_model<SHAPE>), dim3(blocks), dim3(512), 0, 0, out, nch, rounds, cyc);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    CK(hipGetLastError());
+    unsigned long long hc[64];
+    CK(hipMemcpy(hc, cyc, sizeof(hc), hipMemcpyDeviceToHost));
+    double c = 0;
+    for (int i = 0; i < 64; ++i) c += (double)hc[i] / 64;
+    const double bytes = (double)blocks * rounds * 8 * 2560.0;
+    printf("stores %-18s %3d channels per pixel: %7.1f GB/s, %6.0f cycles per group of 8 waves x 16 pixels x 80 channels and CU (%.3f ms, %.2f GHz)\n",
+           label, nch, bytes / best / 1e6, c / rounds, best, c / (best * 1e6));
+}
+
+int main(int argc, char** argv) {
+    const bool only_stores = argc > 1 && argv[1][0] == 's';
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -240,6 +320,14 @@ int main() {
     CK(hipMemset(src, 1, big + (16 << 20)));
     CK(hipMalloc(&out, 4));
     CK(hipMalloc(&cyc, 8 * 4096));
+    if (only_stores) {
+        for (int nch : {160, 320}) {
+            run_store<0>("fragment-shaped", src, nch, cus, cyc);
+            run_store<1>("line-shaped", src, nch, cus, cyc);
+            run_store<2>("contiguous", src, nch, cus, cyc);
+        }
+        return 0;
+    }
     struct { const char* label; size_t span; } spans[] = {{"L2", (size_t)2 << 20}, {"MALL", (size_t)64 << 20}, {"HBM", big}};
     for (auto& sp : spans) {
         const int rounds = 400;
@@ -262,6 +350,11 @@ int main() {
         run_model<true, 3, 2, true>(sp.label, src, src + (4 << 20), sp.span, cus, out, cyc);
         run_model<true, 3, 2, false>(sp.label, src, src + (4 << 20), sp.span, cus, out, cyc);
         run_model<true, 5, 0, true>(sp.label, src, src + (4 << 20), sp.span, cus, out, cyc);
+    }
+    for (int nch : {160, 320}) {
+        run_store<0>("fragment-shaped", src, nch, cus, cyc);
+        run_store<1>("line-shaped", src, nch, cus, cyc);
+        run_store<2>("contiguous", src, nch, cus, cyc);
     }
     return 0;
 }
