@@ -344,6 +344,44 @@ def extra_leg(torch, weights, key, dtype, B, src, what, S, threshold, device, st
         wl.close()
 
 
+def pmc_row_for_cfg(cfg_name):
+    """MFMA-pipe utilisation and shader clock of a tile configuration from the newest committed counter summary
+    (tools/pmc_bench.sh -> profiles/r*_pmc_bench_kernels.json); None when there is none.  A configuration runs as several
+    template instantiations (channel tail, aligned mode): their rows are combined weighted by dispatches x duration, and
+    listed one by one under `instantiations`."""
+    import glob
+    import re
+    m = re.match(r'(v2|v5:run|v5:strip|v7:cont|f8:run)?:?(\d+)x(\d+)/(\d+)x(\d+)', cfg_name)
+    if not m:
+        return None
+    sym = {'v2': 'conv_v2_kernel', 'v5:run': 'conv_v5_kernel', 'f8:run': 'conv_f8_kernel'}.get(m.group(1))
+    if sym is None:
+        return None
+    want = '{}<{}, {}, {}, {}, 0'.format(sym, *m.groups()[1:])            # (PROF = 0: not the developer variants)
+    for ppath in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_bench_kernels.json')), reverse=True):
+        try:
+            rows = {k: r for k, r in json.load(open(ppath)).get('kernels', {}).items() if want in k}
+        except Exception:
+            continue
+        if not rows:
+            continue
+        src = 'profiles/' + os.path.basename(ppath)
+        if len(rows) == 1 or not all('dispatches' in r for r in rows.values()):
+            return dict(next(iter(rows.values())), source=src)
+        w = {k: r['dispatches'] * r['dispatch_us'] for k, r in rows.items()}
+        tot = sum(w.values())
+        clk = [(w[k], r['shader_clock_ghz']) for k, r in rows.items() if r.get('shader_clock_ghz')]
+        out = {'dispatches': sum(r['dispatches'] for r in rows.values()),
+               'dispatch_us': tot / sum(r['dispatches'] for r in rows.values()),
+               'mfma_util_2p4ghz': sum(w[k] * r['mfma_util_2p4ghz'] for k, r in rows.items()) / tot,
+               'shader_clock_ghz': (sum(a * b for a, b in clk) / sum(a for a, _ in clk)) if clk else None,
+               'instantiations': {k[k.index(sym):]: r for k, r in rows.items()}, 'source': src}
+        if clk and all(r.get('mfma_util_measured_clock') for r in rows.values()):
+            out['mfma_util_measured_clock'] = sum(w[k] * r['mfma_util_measured_clock'] for k, r in rows.items()) / tot
+        return out
+    return None
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', '0'))
@@ -518,26 +556,7 @@ def main():
                 e[2] += o['flops']
             top = max(by_cfg.items(), key=lambda kv: kv[1][1])
 
-            def pmc_row(cfg_name):
-                """MFMA-pipe utilisation and shader clock of this kernel instantiation from the newest committed counter
-                summary (tools/pmc_bench.sh -> profiles/r*_pmc_bench_kernels.json); None when there is none"""
-                import glob
-                import re
-                m = re.match(r'(v2|v5:run|v5:strip|v7:cont|f8:run)?:?(\d+)x(\d+)/(\d+)x(\d+)', cfg_name)
-                if not m:
-                    return None
-                sym = {'v2': 'conv_v2_kernel', 'v5:run': 'conv_v5_kernel', 'f8:run': 'conv_f8_kernel'}.get(m.group(1))
-                if sym is None:
-                    return None
-                want = '{}<{}, {}, {}, {}'.format(sym, *m.groups()[1:])
-                for ppath in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_bench_kernels.json')), reverse=True):
-                    try:
-                        for kname, row in json.load(open(ppath)).get('kernels', {}).items():
-                            if want in kname:
-                                return dict(row, source='profiles/' + os.path.basename(ppath))
-                    except Exception:
-                        pass
-                return None
+            pmc_row = pmc_row_for_cfg
             roof['dominant_kernel'] = {
                 'name': ctx.conv_cfg_name(top[0]), 'launches_per_step': top[1][0],
                 'ms_per_step': round(top[1][1], 3), 'avg_launch_us': round(top[1][1] / top[1][0] * 1e3, 2),

@@ -62,7 +62,7 @@ for name in sorted(acc, key=lambda n: -sum(acc[n].get('SQ_BUSY_CYCLES', [0]))):
             clk = 0.0
         per = 2.0 if 'f8' in name else 1.0
         busy = c['SQ_INSTS_MFMA'] * MFMA_CYCLES * per
-        summary[name] = {'dispatch_us': d_ns / 1e3, 'shader_clock_ghz': clk or None,
+        summary[name] = {'dispatches': n, 'dispatch_us': d_ns / 1e3, 'shader_clock_ghz': clk or None,
                          'mfma_util_measured_clock': busy / (N_SIMD * d_ns * clk) if clk > 0 else None,
                          'mfma_util_2p4ghz': busy / (N_SIMD * d_ns * 2.4)}
         if clk > 0:
