@@ -47,6 +47,7 @@ __device__ __forceinline__ float silu_f32(float x) {
 }
 
 constexpr int v2_lds_bytes(int bm, int bn) { return 2 * (bm + bn) * 128; }
+constexpr int v2_ring_lds_bytes(int bm, int bn) { return (3 * bm + 2 * bn) * 128; }
 constexpr int v2_blocks_per_cu(int bm, int bn, int nw) {
     int b = 163840 / v2_lds_bytes(bm, bn);
     if (b > 32 / nw) b = 32 / nw;
@@ -69,7 +70,11 @@ constexpr int v2_waves_per_simd(int bm, int bn, int nw) {
 // place, ConvArgs::in_up); its own instantiation so that the loader of every other launch stays as it was
 // PW = the instantiations for 1x1 / stride 1 / unpadded convs (tile set-up without divisions, see init_tile): 1 = the channel
 // count is a multiple of 64, 2 = it is not (the last K slab's chunks past the last channel are masked, see advance)
-template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false, int PW = 0>
+// RA = activation stages (pointwise instantiations only): 2 = one ring of (activation + weight) stages; 3 = the activation tile in
+// a ring of three beside the weight tile's ring of two -- a short-K pointwise layer is bound by one memory round trip per K step
+// (a two-stage ring prefetches ONE step ahead), its weights come from L2 in a third of the time its activations take from the
+// memory side, so the LDS a third weight stage would need buys more as activation lead (DESIGN.md section 5 [r4])
+template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false, int PW = 0, int RA = 2>
 __global__ void __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BM, BN, WM * WN))
 conv_v2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -81,6 +86,10 @@ conv_v2_kernel(const ConvArgs p) {
     constexpr int A_PER = BM / 8 / NW, B_PER = (B_INSTR + NW - 1) / NW;
     constexpr bool B_RAGGED = (B_INSTR % NW) != 0;        // the last piece exists only on the first waves
     static_assert((BM / 8) % NW == 0, "the activation tile must split evenly over the waves");
+    static_assert(RA == 2 || (RA == 3 && PW != 0 && !UP), "the three-stage activation ring is a pointwise instantiation");
+    // byte offsets of activation stage sa / weight stage sb
+    auto a_stage = [](int sa) __attribute__((always_inline)) { return RA == 2 ? sa * STAGE : sa * A_BYTES; };
+    auto b_stage = [](int sb) __attribute__((always_inline)) { return RA == 2 ? sb * STAGE + A_BYTES : RA * A_BYTES + sb * B_BYTES; };
     static_assert(TM % 16 == 0 && TN % 16 == 0 && TM % 8 == 0, "wave tile must be a multiple of 16x16");
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
@@ -133,6 +142,7 @@ conv_v2_kernel(const ConvArgs p) {
     unsigned tapoff = 0;
     int l_kt = 0, l_tile = first_tile;
     bool l_live = true;                     // false once the stream has no more slabs to load
+    [[maybe_unused]] int lb_kt = 0;         // (RA == 3) the weight loader's slab: it runs one step behind the activation loader
     const int kh = p.ntaps / p.kw;
     const unsigned wrap_c = (unsigned)(p.ld_in * 2 - p.C8 * 16);        // next tap, same row
     const unsigned wrap_r = (unsigned)((p.W - p.kw) * p.ld_in * 2);     // first tap of the next kernel row
@@ -256,7 +266,7 @@ conv_v2_kernel(const ConvArgs p) {
             }
         }
         if constexpr (PW) {
-            MDHIP_DMA16(a_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, a_off[i], l_kt * 128);
+            MDHIP_DMA16(a_rsrc, smem + a_stage(buf) + (i * NW + wave) * 1024, a_off[i], l_kt * 128);
         } else {
             const unsigned voff = (a_mask[i] & tapbit) ? a_off[i] + tapoff : kOOB;
             MDHIP_DMA16(a_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, voff, 0);
@@ -267,22 +277,22 @@ conv_v2_kernel(const ConvArgs p) {
         if (B_RAGGED && i == B_PER - 1 && wave >= B_INSTR % NW) return;     // wave-uniform
         // (PW: after the stream's last slab the loader re-reads slabs of the last tile into stages nobody reads)
         const unsigned voff = (PW || l_live) ? b_off[i] : kOOB;
-        MDHIP_DMA16(b_rsrc, smem + buf * STAGE + A_BYTES + (i * NW + wave) * 1024, voff, l_kt * 128);
+        MDHIP_DMA16(b_rsrc, smem + b_stage(buf) + (i * NW + wave) * 1024, voff, (RA == 3 ? lb_kt : l_kt) * 128);
     };
 
     // ---- fragment reads ---------------------------------------------------------------------------
     const int frag_row_off = (lane & 15) * 128;
     const int frag_ch0 = (((lane >> 4) ^ (lane & 7)) * 16);      // k 0..31 ; k 32..63 is ^ 64
     const int a_frag_base = (wm * TM) * 128 + frag_row_off;
-    const int b_frag_base = A_BYTES + (wn * TN) * 128 + frag_row_off;
+    const int b_frag_base = (wn * TN) * 128 + frag_row_off;
     auto read_x = [&](int buf, int kk, int i) -> frag8_t {
         if constexpr ((PROF & 32) != 0) return frag_dummy(lane + i);
-        return *(const __attribute__((address_space(3))) frag8_t*)(smem + buf * STAGE + a_frag_base + i * 2048 +
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + a_stage(buf) + a_frag_base + i * 2048 +
                                                                  (frag_ch0 ^ (kk * 64)));
     };
     auto read_w = [&](int buf, int kk, int j) -> frag8_t {
         if constexpr ((PROF & 32) != 0) return frag_dummy(lane + j);
-        return *(const __attribute__((address_space(3))) frag8_t*)(smem + buf * STAGE + b_frag_base + j * 2048 +
+        return *(const __attribute__((address_space(3))) frag8_t*)(smem + b_stage(buf) + b_frag_base + j * 2048 +
                                                                  (frag_ch0 ^ (kk * 64)));
     };
 
@@ -471,16 +481,33 @@ conv_v2_kernel(const ConvArgs p) {
 
     // ---- prologue: slabs 0 and 1 in flight, fragments X of slab 0 in registers ---------------------
     init_tile(first_tile);
+    auto lb_advance = [&]() __attribute__((always_inline)) { lb_kt = (lb_kt + 1 == KT) ? 0 : lb_kt + 1; };
+    if constexpr (RA == 3) {
+        // activation slabs 0, 1, 2 and weight slabs 0, 1
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) dma_a(0, i);
+        for (int st = 0; st < 3; ++st) {
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) dma_b(0, i);
-    advance();
+            for (int i = 0; i < A_PER; ++i) dma_a(st, i);
+            advance();
+        }
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) dma_a(1, i);
+        for (int st = 0; st < 2; ++st) {
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) dma_b(1, i);
-    advance();
+            for (int i = 0; i < B_PER; ++i) dma_b(st, i);
+            lb_advance();
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) dma_a(0, i);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) dma_b(0, i);
+        advance();
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) dma_a(1, i);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) dma_b(1, i);
+        advance();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -500,8 +527,11 @@ conv_v2_kernel(const ConvArgs p) {
         }
     };
     if constexpr ((PROF & 1) != 0) t_prev = __builtin_amdgcn_s_memtime();
+    [[maybe_unused]] int ca = 0;                    // (RA == 3) activation stage of the step being computed: step % 3
     for (int step = 0; step < total_steps; ++step) {
         const int cur = step & 1;
+        // activation stages of this step / of the next one (the weight stages are cur / cur ^ 1)
+        const int xa_cur = RA == 3 ? ca : cur, xa_nxt = RA == 3 ? (ca == 2 ? 0 : ca + 1) : cur ^ 1;
         // The instruction mix of a step is pinned with sched_barrier(0) fences: left alone the compiler
         // sinks all fragment reads below the MFMAs of a half (the wave then waits for them at the
         // barrier) and issues the DMA pieces as one burst.  None of the reads of a half is consumed
@@ -511,10 +541,10 @@ conv_v2_kernel(const ConvArgs p) {
 #pragma unroll
         for (int g = 0; g < FN; ++g) {
             wb[g] = read_w(cur, 1, g);
-            if (g < FM) xb[g] = read_x(cur, 1, g);
+            if (g < FM) xb[g] = read_x(xa_cur, 1, g);
             if (g == FN - 1) {
 #pragma unroll
-                for (int i = FN; i < FM; ++i) xb[i] = read_x(cur, 1, i);
+                for (int i = FN; i < FM; ++i) xb[i] = read_x(xa_cur, 1, i);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((PROF & 64) == 0) {
@@ -527,7 +557,10 @@ conv_v2_kernel(const ConvArgs p) {
 
         stamp(0);
         // slab step+1 has landed (this wave's pieces), stage `cur` is fully in registers
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // (RA == 3: the activation pieces of slab step+2, issued BEHIND the weight pieces of slab step+1 in the half step before,
+        // may still be in flight: loads complete in order)
+        if constexpr (RA == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         stamp(1);
         __builtin_amdgcn_s_barrier();
         stamp(2);
@@ -538,10 +571,10 @@ conv_v2_kernel(const ConvArgs p) {
 #pragma unroll
         for (int g = 0; g < FN; ++g) {
             wa[g] = read_w(cur ^ 1, 0, g);
-            if (g < FM) xa[g] = read_x(cur ^ 1, 0, g);
+            if (g < FM) xa[g] = read_x(xa_nxt, 0, g);
             if (g == FN - 1) {
 #pragma unroll
-                for (int i = FN; i < FM; ++i) xa[i] = read_x(cur ^ 1, 0, i);
+                for (int i = FN; i < FM; ++i) xa[i] = read_x(xa_nxt, 0, i);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((PROF & 64) == 0) {
@@ -552,14 +585,24 @@ conv_v2_kernel(const ConvArgs p) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int d = g * DMA_PER_G; d < (g + 1) * DMA_PER_G && d < DMA_TOTAL; ++d) {
-                if (d < A_PER) dma_a(cur, d);
-                else dma_b(cur, d - A_PER);
+                if constexpr (RA == 3) {
+                    // weight slab step+2 first, then activation slab step+3 into the stage this step has just finished with
+                    if (d < B_PER) dma_b(cur, d);
+                    else dma_a(xa_cur, d - B_PER);
+                } else {
+                    if (d < A_PER) dma_a(cur, d);
+                    else dma_b(cur, d - A_PER);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 
         stamp(3);
         advance();
+        if constexpr (RA == 3) {
+            lb_advance();
+            ca = ca == 2 ? 0 : ca + 1;
+        }
         stamp(4);
         if (++c_kt == KT) {
             epilogue(c_tile);
@@ -593,20 +636,30 @@ conv_v2_kernel(const ConvArgs p) {
     X(6, 192, 160, 4, 2)    \
     X(7, 256, 160, 4, 2)    \
     X(8, 320, 160, 4, 2)
+// pointwise-only configurations with the three-stage activation ring (RA = 3): id, BM, BN, WM, WN
+#define MDHIP_CONV2_RING(X) \
+    X(9, 96, 160, 2, 2)     \
+    X(10, 64, 160, 1, 2)    \
+    X(11, 320, 160, 4, 2)   \
+    X(12, 256, 160, 4, 2)
 // id, BM, BN, WM, WN, PROF bits (1 = s_memtime stamps, 2 = no stores, 4 = no SiLU)
 #define MDHIP_CONV2_PROF(X) \
-    X(9, 160, 160, 2, 2, 1)  \
-    X(10, 320, 160, 4, 2, 1) \
-    X(11, 160, 160, 2, 2, 54) \
-    X(12, 320, 160, 4, 2, 22) \
-    X(13, 320, 160, 4, 2, 16) \
-    X(14, 160, 160, 2, 2, 16)
+    X(13, 160, 160, 2, 2, 1)  \
+    X(14, 320, 160, 4, 2, 1) \
+    X(15, 160, 160, 2, 2, 54) \
+    X(16, 320, 160, 4, 2, 22) \
+    X(17, 320, 160, 4, 2, 16) \
+    X(18, 160, 160, 2, 2, 16)
 
 static const ConvCfg g_cfgs2[] = {
 #define X(id, bm, bn, wm, wn)                                                                        \
     {bm, bn, (wm) * (wn) * 64, (size_t)v2_lds_bytes(bm, bn), v2_blocks_per_cu(bm, bn, (wm) * (wn)), \
      "v2:" #bm "x" #bn "/" #wm "x" #wn},
     MDHIP_CONV2_CFGS(X)
+#undef X
+#define X(id, bm, bn, wm, wn)                                                                        \
+    {bm, bn, (wm) * (wn) * 64, (size_t)v2_ring_lds_bytes(bm, bn), 163840 / v2_ring_lds_bytes(bm, bn) >= 2 ? 2 : 1, "v2:" #bm "x" #bn "/" #wm "x" #wn "/a3"},
+    MDHIP_CONV2_RING(X)
 #undef X
 #define X(id, bm, bn, wm, wn, prof)                                                                  \
     {bm, bn, (wm) * (wn) * 64, (size_t)v2_lds_bytes(bm, bn), v2_blocks_per_cu(bm, bn, (wm) * (wn)), \
@@ -633,6 +686,15 @@ hipError_t conv2_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
     MDHIP_CONV2_CFGS(X)
 #undef X
+#define X(id, bm, bn, wm, wn)                                                                        \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, 1, 3>,          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes); \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, 2, 3>,          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
+    MDHIP_CONV2_RING(X)
+#undef X
 #define X(id, bm, bn, wm, wn, prof)                                                                  \
     if (e == hipSuccess)                                                                           \
         e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, prof>,                       \
@@ -645,6 +707,11 @@ hipError_t conv2_init() {
     return e;
 }
 
+// (the configurations with a three-stage activation ring: 1x1 / stride 1 / unpadded launches only, at least three K slabs)
+bool conv2_cfg_is_ring(int cfg) { return cfg >= 9 && cfg < conv2_num_cfgs(); }
+bool conv2_is_pointwise(const ConvArgs& a) {
+    return a.ntaps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.in_up == nullptr;
+}
 bool conv2_supports(const ConvArgs& a) {
     // the branch-free K walk needs at least one whole slab per tap; the epilogue stores 4 channels
     // (in_up goes with configuration 0 only: the family table in conv_igemm.cpp checks the id)
@@ -678,6 +745,14 @@ hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         break;
         MDHIP_CONV2_CFGS(X)
+#undef X
+#define X(id, bm, bn, wm, wn)                                                                        \
+    case id:                                                                                       \
+        if (!pw) return hipErrorInvalidValue;                                                      \
+        if ((a.C8 & 7) == 0) hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, 1, 3>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        else hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, 2, 3>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        break;
+        MDHIP_CONV2_RING(X)
 #undef X
 #define X(id, bm, bn, wm, wn, prof)                                                                  \
     case id:                                                                                       \

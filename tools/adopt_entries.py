@@ -21,6 +21,9 @@ def main():
     ap.add_argument('table')
     ap.add_argument('--min-gain', type=float, default=0.03)
     ap.add_argument('--prefix', default='v7:')
+    ap.add_argument('--no-propagate', action='store_true',
+                    help='the adopted configurations belong to the bitwise family of the entries they replace (same K order): the '
+                         'entries of the other batch sizes keep their own measured configurations')
     ap.add_argument('--names', required=True, help='json list of configuration names by id (mdhip_conv_cfg_name), for the table columns')
     a = ap.parse_args()
     names = json.load(open(a.names))
@@ -62,7 +65,7 @@ def main():
     moved = 0
     for e in old.values():
         top = lead[geo(e)]
-        if str(top.get('name', '')).startswith(a.prefix) and e.get('name') != top['name']:
+        if not a.no_propagate and str(top.get('name', '')).startswith(a.prefix) and e.get('name') != top['name']:
             e['name'], e['cfg'] = top['name'], top['cfg']
             e.pop('ms', None)
             e.pop('tflops', None)
