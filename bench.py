@@ -63,7 +63,7 @@ def parse_args():
                          "measured, no gain (profiles/r3_graph_replay.txt)")
     ap.add_argument('--lean', action='store_true',
                     help='only warm-up + timed steps (no per-stage / per-op extras): for rocprofv3 runs')
-    ap.add_argument('--cpu-seconds', type=float, default=14.0)
+    ap.add_argument('--cpu-seconds', type=float, default=24.0)
     ap.add_argument('--no-cpu-single-thread', action='store_true', help='skip the one-thread CPU row (one image, ~1 min)')
     ap.add_argument('--nms-inline', action='store_true',
                     help='NMS + D2H of step i on the compute stream behind the forward (rounds 2-3 default).  Default since '
@@ -81,11 +81,36 @@ def parse_args():
                     help='skip the short legs of the other BASELINE configurations (extra_configs: fp8 batch 64, 1080p video '
                          'frames, 4:3 real shape, fp16 storage); they only run with the default headline workload on one GPU')
     ap.add_argument('--extra-steps', type=int, default=10)
+    ap.add_argument('--pin-cpus', action='store_true',
+                    help='N = 1: pin this process to the CPUs of the GPU\'s NUMA node anyway (placement.pin_worker(force=True); '
+                         'with N > 1 every rank is pinned by default, MDHIP_NO_PINNING=1 switches that off)')
+    ap.add_argument('--rendezvous-check', action='store_true',
+                    help='launch-contract check without a GPU: every rank joins a gloo group, rank 0 prints {"n_gpus": world, '
+                         '"ranks": [...]} and exits (tests/test_bench_launch.py runs `bench.py --gpus 2 --rendezvous-check`)')
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: become the launcher the driver would be --
+    one rank per GPU through torch.distributed.run on 127.0.0.1 (the reference's recipe is one command per GPU,
+    notebooks/manage_local_batch.py:617-621) -- and hand its exit code on.  Rank 0 of that run prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    print('bench.py: --gpus {} without WORLD_SIZE: launching {}'.format(args.gpus, ' '.join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
-    """The oracle (CPU restatement of the reference's path) timed on this host's cores."""
+    """The oracle (CPU restatement of the reference's path) timed on this host's cores: the thread count that does best
+    on this box (a sweep of one image each over {8, 16, 32, 64, all}: batch-1 convs on all 128 threads of the bench host
+    are oversubscribed), then the rest of the budget at that count; forward and NMS + formatting seconds apart."""
     import torch
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     import parity_util as PU
@@ -94,26 +119,50 @@ def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
     fw = Y.Forward(weights.yaml, weights.torch_state(), emulate_bf16=False)
     imgs = PU.random_images(2, size, size, seed=100)
 
-    def one(img):
+    def one(img, split=None):
+        t0 = time.perf_counter()
         x, infos = PU.oracle_input([img], size, weights.max_stride)
         with torch.no_grad():
             pred = fw(x)
-        return PU.oracle_detections(pred, infos, tuple(x.shape[2:]), threshold)
+        t1 = time.perf_counter()
+        out = PU.oracle_detections(pred, infos, tuple(x.shape[2:]), threshold)
+        if split is not None:
+            split[0] += t1 - t0
+            split[1] += time.perf_counter() - t1
+        return out
 
     small = PU.random_images(1, 256, 256, seed=1)[0]
     one(small)                                   # warm-up (thread pools, allocator)
+    t_all = time.perf_counter()
+    counts = sorted(set(c for c in (8, 16, 32, 64) if c < cores) | {cores})
+    sweep = {}
+    for c in counts:
+        torch.set_num_threads(c)
+        one(small)
+        t0 = time.perf_counter()
+        one(imgs[0])
+        sweep[c] = time.perf_counter() - t0
+        if time.perf_counter() - t_all > 0.7 * budget_s and len(sweep) >= 2:
+            break                                # a slow host: the counts tried so far have to do
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    split = [0.0, 0.0]
     t0 = time.perf_counter()
     n = 0
     while True:
-        one(imgs[n % 2])
+        one(imgs[n % 2], split)
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 16:
+        if el >= max(0.4 * budget_s, budget_s - (t0 - t_all)) or n >= 16:
             break
-    res = {'value': n / el, 'unit': 'images/s', 'cores': int(cores), 'kind': 'port',
+    torch.set_num_threads(cores)
+    res = {'value': n / el, 'unit': 'images/s', 'cores': int(best), 'kind': 'port',
+           'host_threads_available': int(cores),
+           'thread_sweep_images_per_s': {str(c): round(1.0 / t, 4) for c, t in sweep.items()},
+           'forward_s_per_image': round(split[0] / n, 3), 'nms_format_s_per_image': round(split[1] / n, 3),
            'sample': '{} synthetic {}x{} images, batch 1 (CPU batch size is forced to 1 by the '
-                     'reference), oracle fp32 torch-CPU forward + NMS + formatting, {:.1f} s'.format(
-                         n, size, size, el)}
+                     'reference), oracle fp32 torch-CPU forward + NMS + formatting, {:.1f} s at {} threads (the best of a '
+                     'one-image sweep over {} threads)'.format(n, size, size, el, best, '/'.join(str(c) for c in sweep))}
     if single_thread:
         # one thread, comparable to the published single-core figures
         # (reference megadetector.md:358-359: 0.5-0.8 images/s per core class); ONE image bounds the cost
@@ -384,9 +433,29 @@ def pmc_row_for_cfg(cfg_name):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus {} but WORLD_SIZE={}: launch with --nproc-per-node {} (or without a launcher: '
+                         '`python bench.py --gpus N` starts the ranks itself)'.format(args.gpus, world, args.gpus))
+    if args.rendezvous_check:
+        import torch
+        import torch.distributed as dist
+        got = [rank]
+        if world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            allr = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(allr, torch.tensor([rank], dtype=torch.int64))
+            got = [int(t.item()) for t in allr]
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({'n_gpus': world, 'ranks': got, 'rendezvous_check': True}))
+        return
     import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)')
@@ -399,8 +468,9 @@ def main():
     # one rank per GPU: CPUs of the GPU's NUMA node, disjoint from the other ranks' (the host thread formats 2.8 ms of
     # detections per step and keeps the queue fed; SURVEY.md 8(e) "scaling limiter")
     from megadetector_amd import placement
-    pinned_cpus = placement.pin_worker(local_rank, 1 if one_gpu else int(os.environ.get('LOCAL_WORLD_SIZE', world)), verbose=False)
-    if world > 1:                                              # stdout carries the one JSON line and nothing else
+    pinned_cpus = placement.pin_worker(local_rank, 1 if one_gpu else int(os.environ.get('LOCAL_WORLD_SIZE', world)), verbose=False,
+                                       force=args.pin_cpus)
+    if world > 1 or args.pin_cpus:                             # stdout carries the one JSON line and nothing else
         print('rank {}: {} CPUs{}'.format(rank, len(pinned_cpus), ' ({}..{})'.format(pinned_cpus[0], pinned_cpus[-1])
                                           if pinned_cpus else ''), file=sys.stderr)
     dist = None
@@ -653,6 +723,7 @@ def main():
             'stages': stages,
             'extra_configs': extra,
             'per_rank_images_per_s': per_rank,
+            'pinned_cpus': len(pinned_cpus) if (world > 1 or args.pin_cpus) else None,
         }
         print(json.dumps(line))
     if dist is not None:

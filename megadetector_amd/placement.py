@@ -124,13 +124,21 @@ def plan(n_gpus, topology):
     return out
 
 
-def pin_worker(gpu, n_gpus, topology=None, verbose=True):
+def pin_worker(gpu, n_gpus, topology=None, verbose=True, force=False):
     """Restricts the calling process (and everything it spawns later) to its share of the CPUs; returns the CPU list.
-    MDHIP_NO_PINNING=1 switches it off."""
-    if os.environ.get('MDHIP_NO_PINNING') == '1' or not hasattr(os, 'sched_setaffinity') or n_gpus <= 1:
+    MDHIP_NO_PINNING=1 switches it off.  A lone worker (n_gpus <= 1) keeps the whole machine unless `force` (or
+    MDHIP_PIN_SINGLE=1) asks for the CPUs of its GPU's NUMA node: `bench.py --pin-cpus`, the detector option
+    'pin_cpus' and the image / video drivers' single-GPU runs on a two-socket host."""
+    force = force or os.environ.get('MDHIP_PIN_SINGLE') == '1'
+    if os.environ.get('MDHIP_NO_PINNING') == '1' or not hasattr(os, 'sched_setaffinity') or (n_gpus <= 1 and not force):
         return sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
-    topology = topology or read_topology(n_gpus)
-    cpus = plan(n_gpus, topology)[gpu]
+    n_gpus = max(1, n_gpus)
+    if topology is None:
+        # a lone worker on GPU g still needs the node of GPU g: read the topology up to and including that ordinal
+        topology = read_topology(max(n_gpus, gpu + 1))
+        if n_gpus == 1:
+            topology = dict(topology, gpu_node=[topology['gpu_node'][gpu]])
+    cpus = plan(n_gpus, topology)[gpu if n_gpus > 1 else 0]
     try:
         # every thread of the process, not only the caller: sched_setaffinity(0, ...) pins the calling THREAD on Linux,
         # and the runtime threads that torch / numpy / the HIP runtime started while importing would keep the full mask
@@ -148,7 +156,7 @@ def pin_worker(gpu, n_gpus, topology=None, verbose=True):
         print('Warning: could not pin the worker of GPU {} to CPUs {}: {}'.format(gpu, cpus, e))
         return sorted(os.sched_getaffinity(0))
     if verbose:
-        node = (topology.get('gpu_node') or [-1] * n_gpus)[gpu]
+        node = (topology.get('gpu_node') or [-1] * n_gpus)[gpu if n_gpus > 1 else 0]
         print('GPU {} worker pinned to {} CPUs (NUMA node {}): {}..{}'.format(gpu, len(cpus), node, cpus[0], cpus[-1]))
     return cpus
 
