@@ -400,16 +400,24 @@ def pmc_row_for_cfg(cfg_name):
     listed one by one under `instantiations`."""
     import glob
     import re
-    m = re.match(r'(v2|v5:run|v5:strip|v7:cont|f8:run)?:?(\d+)x(\d+)/(\d+)x(\d+)', cfg_name)
+    m = re.match(r'(v2|v5:run|v5:strip|v7:s2run|f8:run)?:?(\d+)x(\d+)/(\d+)x(\d+)', cfg_name)
     if not m:
         return None
-    sym = {'v2': 'conv_v2_kernel', 'v5:run': 'conv_v5_kernel', 'f8:run': 'conv_f8_kernel'}.get(m.group(1))
+    sym = {'v2': 'conv_v2_kernel', 'v5:run': 'conv_v5_kernel', 'f8:run': 'conv_f8_kernel', 'v7:s2run': 'conv_v7_kernel'}.get(m.group(1))
     if sym is None:
         return None
-    want = '{}<{}, {}, {}, {}, 0'.format(sym, *m.groups()[1:])            # (PROF = 0: not the developer variants)
+    if sym == 'conv_v7_kernel':
+        want = 'conv_v7_kernel<'                                          # one tile shape: <channel-tail mode, aligned>
+        keep = lambda k: True
+    else:
+        want = '{}<{}, {}, {}, {}, 0'.format(sym, *m.groups()[1:])        # (PROF = 0: not the developer variants)
+        # conv_v2_kernel<BM, BN, WM, WN, PROF, upsample-reading, tail mode, activation ring stages>: a '/a3' configuration
+        # is the three-stage ring instantiation, every other v2 name the two-stage one
+        ring3 = cfg_name.endswith('/a3')
+        keep = (lambda k: k.rstrip().endswith(', 3>') == ring3) if sym == 'conv_v2_kernel' else (lambda k: True)
     for ppath in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_bench_kernels.json')), reverse=True):
         try:
-            rows = {k: r for k, r in json.load(open(ppath)).get('kernels', {}).items() if want in k}
+            rows = {k: r for k, r in json.load(open(ppath)).get('kernels', {}).items() if want in k and keep(k)}
         except Exception:
             continue
         if not rows:

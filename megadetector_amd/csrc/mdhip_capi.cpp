@@ -171,6 +171,10 @@ struct mdhip_ctx {
     // the input tensor
     hipEvent_t input_free = nullptr;
     bool input_free_valid = false;
+    // the NMS that reads prediction buffer k (possibly on another stream: mdhip_nms_enqueue) records pred_read[k]; the
+    // forward that is about to overwrite buffer k waits for it -- the ordering is the library's, not the caller's
+    hipEvent_t pred_read[2] = {nullptr, nullptr};
+    bool pred_read_valid[2] = {false, false};
 };
 
 namespace {
@@ -190,7 +194,10 @@ int fail(mdhip_ctx* ctx, int code, const char* fmt, ...) {
 void drop_graphs(mdhip_ctx* ctx) {
     bool any = false;
     for (auto& kv : ctx->graphs) any |= kv.second.exec != nullptr;
-    if (any) (void)hipDeviceSynchronize();
+    if (any) {
+        (void)hipSetDevice(ctx->device);            // (the setters reach here without it: synchronise OUR device)
+        (void)hipDeviceSynchronize();
+    }
     for (auto& kv : ctx->graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     ctx->graphs.clear();
@@ -205,6 +212,7 @@ void evict_graph_if_full(mdhip_ctx* ctx) {
     for (auto it = ctx->graphs.begin(); it != ctx->graphs.end(); ++it)
         if (it->second.exec && (victim == ctx->graphs.end() || it->second.last_use < victim->second.last_use)) victim = it;
     if (victim == ctx->graphs.end()) return;
+    (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     (void)hipGraphExecDestroy(victim->second.exec);
     ctx->graphs.erase(victim);
@@ -1195,12 +1203,21 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
         }                                                                                       \
     } while (0)
 
+    // mdhip_forward records `input_free` right behind op 0: nothing after it may read the network input
+    for (size_t oi = 1; oi < ctx->ops.size(); ++oi)
+        if ((ctx->ops[oi].in.valid && ctx->ops[oi].in.off == ctx->input.off) ||
+            (ctx->ops[oi].has_res && ctx->ops[oi].res.off == ctx->input.off)) {
+            const std::string m = "op " + std::to_string(oi) + " (" + ctx->ops[oi].name + ") reads the network input: only layer 0 may";
+            mdhip_destroy(ctx);
+            return fail(nullptr, MDHIP_EINVAL, "%s", m.c_str());
+        }
     CREATE_TRY(hipMalloc((void**)&ctx->arena, ctx->arena_bytes));
     CREATE_TRY(hipMalloc((void**)&ctx->warena, ctx->warena_bytes));
     CREATE_TRY(hipMemset(ctx->warena, 0, 256));
     CREATE_TRY(hipHostMalloc((void**)&ctx->geom_host, (size_t)4 * max_batch * sizeof(LetterboxDev), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreateWithFlags(&ctx->geom_ev[i], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->input_free, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) CREATE_TRY(hipEventCreateWithFlags(&ctx->pred_read[i], hipEventDisableTiming));
     for (int i = 0; i < MDHIP_NMS_SLOTS; ++i) {
         CREATE_TRY(hipHostMalloc((void**)&ctx->nms_host_out[i], (size_t)max_batch * kNmsMaxDet * 6 * 4, hipHostMallocDefault));
         CREATE_TRY(hipHostMalloc((void**)&ctx->nms_host_cnt[i], (size_t)max_batch * 4, hipHostMallocDefault));
@@ -1254,6 +1271,8 @@ void mdhip_destroy(mdhip_ctx* ctx) {
     if (ctx->geom_host) (void)hipHostFree(ctx->geom_host);
     for (int i = 0; i < 4; ++i) if (ctx->geom_ev[i]) (void)hipEventDestroy(ctx->geom_ev[i]);
     if (ctx->input_free) (void)hipEventDestroy(ctx->input_free);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->pred_read[i]) (void)hipEventDestroy(ctx->pred_read[i]);
     for (int i = 0; i < MDHIP_NMS_SLOTS; ++i) {
         if (ctx->nms_host_out[i]) (void)hipHostFree(ctx->nms_host_out[i]);
         if (ctx->nms_host_cnt[i]) (void)hipHostFree(ctx->nms_host_cnt[i]);
@@ -1322,8 +1341,10 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
     memcpy(gh, g.data(), n * sizeof(LetterboxDev));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->arena + ctx->geom_off, gh, n * sizeof(LetterboxDev), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipEventRecord(ctx->geom_ev[slot], s));
+    bool no_resampling = getenv("MDHIP_LETTERBOX_GENERAL") == nullptr;
+    for (int i = 0; i < n; ++i) no_resampling = no_resampling && g[i].resized_h == g[i].src_h && g[i].resized_w == g[i].src_w;
     HIP_TRY(ctx, launch_letterbox_s2d((const LetterboxDev*)(ctx->arena + ctx->geom_off), n, out_h, out_w,
-                                      (uint16_t*)(ctx->arena + ctx->input.off), ctx->dtype == MDHIP_DTYPE_FP16, s));
+                                      (uint16_t*)(ctx->arena + ctx->input.off), ctx->dtype == MDHIP_DTYPE_FP16, no_resampling, s));
     ctx->last_n = n;
     ctx->last_h = out_h;
     ctx->last_w = out_w;
@@ -1342,6 +1363,8 @@ int mdhip_forward(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     ctx->cur_A = num_anchors_for(ctx, h, w);
     ctx->pred_cur ^= 1;
     ctx->pred_off = ctx->pred_offs[ctx->pred_cur];
+    if (ctx->pred_read_valid[ctx->pred_cur])            // an NMS on another stream may still read the buffer this forward overwrites
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pred_read[ctx->pred_cur], 0));
     const bool use_graph = (ctx->graph_mode == 1 || (ctx->graph_mode == 2 && n <= ctx->graph_max_n)) && !ctx->calibrating;
     bool launched = false;
     if (use_graph) {
@@ -1439,6 +1462,8 @@ int mdhip_forward_tta(mdhip_ctx* ctx, int n, int h, int w, void* hip_stream) {
     ctx->cur_A = total;
     ctx->pred_cur ^= 1;
     ctx->pred_off = ctx->pred_offs[ctx->pred_cur];
+    if (ctx->pred_read_valid[ctx->pred_cur])            // an NMS on another stream may still read the buffer this forward overwrites
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pred_read[ctx->pred_cur], 0));
     int out_off = 0;
     for (int k = 0; k < 3; ++k) {
         if (k) HIP_TRY(ctx, launch_tta_scale(orig, in, n, h, w, sh[k], sw[k], oh[k], ow[k], flips[k], f16, s));
@@ -1672,6 +1697,8 @@ int mdhip_nms_enqueue(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, 
     int* cnt_dev = (int*)(ctx->arena + ctx->nms_cnt_off);
     HIP_TRY(ctx, launch_nms((const float*)(ctx->arena + ctx->pred_off), n, A, ctx->no, conf_thres, iou_thres, max_det,
                             ctx->nms_scr, out_dev, cnt_dev, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->pred_read[ctx->pred_cur], s));
+    ctx->pred_read_valid[ctx->pred_cur] = true;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nms_host_out[slot], out_dev, (size_t)n * max_det * 6 * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nms_host_cnt[slot], cnt_dev, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(ctx->nms_ev[slot], s));

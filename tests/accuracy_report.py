@@ -30,10 +30,14 @@ def main():
     cases.append(('checkpoint (fake_yolov5 S6)', weights_io.load_checkpoint('/tmp/acc_fake.pt')))
     if '--x6' in sys.argv:
         # the headline topology: seeded weights as bench.py uses them, and checkpoint files with non-trivial
-        # BatchNorm statistics at two conditioning levels (gain 1.3: a perturbation does not grow through the head,
-        # like a trained network; 1.75: it grows ~4x per head C3 -- tests/fake_yolov5.build_model)
+        # BatchNorm statistics at five conditioning levels (gain 1.3: a perturbation does not grow through the head --
+        # and the input-dependent part of the signal dies with it; 1.5 / 1.65: intermediate; 1.7: the edge, the
+        # input-dependent signal survives to the logits (standard deviation 0.2 .. 0.7 per anchor plane) and so does every
+        # rounding; 1.75: chaotic, a perturbation grows ~4x per head C3 -- tests/fake_yolov5.build_model).  The column
+        # 'signal' is the standard deviation of the objectness logit over the positions of one anchor plane (median
+        # over the planes): what the errors have to be read against
         cases = [('synthetic YOLOV5X6_MD (bench weights)', weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0))]
-        for gain in (1.3, 1.75):
+        for gain in (1.3, 1.5, 1.65, 1.7, 1.75):
             model = FY.build_model(yolo_yaml.YOLOV5X6_MD, seed=7, gain=gain)
             FY.save_checkpoint(model, '/tmp/acc_fake_x6.pt')
             del model
@@ -46,6 +50,17 @@ def main():
     for label, W in cases:
         p32, _ = PU.oracle_forward(W, x, emulate_bf16=False)
         p32 = p32.numpy()
+        with np.errstate(all='ignore'):
+            lg = np.log(np.clip(p32[..., 4], 1e-30, 1.0) / np.clip(1.0 - p32[..., 4], 1e-30, 1.0)).astype(np.float64)
+        planes, a0 = [], 0
+        from megadetector_amd.yolo_model import model_strides, resolve_yaml
+        for stride in model_strides(resolve_yaml(W.yaml)):
+            cnt = (hh // int(stride)) * (ww // int(stride))
+            for a in range(3):
+                planes.append(float(lg[:, a0 + a * cnt:a0 + (a + 1) * cnt].std()))
+            a0 += 3 * cnt
+        print('{:38s} signal: objectness-logit std per anchor plane, median {:.3f} (min {:.3f}, max {:.3f})'.format(
+            label, float(np.median(planes)), min(planes), max(planes)))
         for dtype in ('bf16', 'fp16', 'fp8'):
             ctx = HipContext(W, device=0, dtype=dtype, max_batch=2, max_h=hh, max_w=ww)
             ctx.preprocess(imgs, [(hh, ww, hh, ww, 0, 0)] * 2, hh, ww)

@@ -228,6 +228,71 @@ def build_model(yaml, seed=0, gain=1.75):
     return model.eval()
 
 
+def sparsify_objectness(model, x, score_thr=0.2, per_plane=(2, 6), logit_std=0.5):
+    """
+    Turns the dense, nearly input-independent predictions of a random-weight model into a camera-trap-like SPARSE set
+    on the batch x.  A contractive random network (gain 1.3) forgets its input: the objectness logits of one (Detect
+    level, anchor) plane differ by 0.01 .. 0.05 over all positions of all images, so any bias switches whole planes on
+    or off.  Here, per plane,
+      * the objectness row of the Detect conv is scaled so that the plane's logits have a standard deviation of
+        `logit_std` over the batch (the bias keeps the plane's mean where it was) -- the rounding noise of a reduced
+        storage type is amplified by the same factor, so `logit_std` IS the conditioning of the fixture (0.5: the
+        input-dependent signal is 50 .. 100x a 16-bit mantissa's noise in fp16, 6 .. 12x in bf16);
+      * the bias is then shifted so that only the k most confident anchors of the plane (per_plane[0] <= k <=
+        per_plane[1], over the whole batch) have  obj * max(cls) > score_thr, k chosen so that the threshold falls into
+        the WIDEST gap between consecutive scores: no anchor sits on the threshold, where a rounding difference would
+        create / remove a detection (the reference's own comparison avoids that by running at its output threshold
+        0.005 = its confidence bar, md_tests.py:100).
+    Returns the number of anchors above the threshold per image.
+    """
+    common, yolo = _install()
+    det = [m for m in model.modules() if isinstance(m, yolo.Detect)][0]
+    with torch.no_grad():
+        feats = {}
+        hooks = [conv.register_forward_pre_hook(lambda mod, inp, i=i: feats.__setitem__(i, inp[0].detach().double()))
+                 for i, conv in enumerate(det.m)]
+        model(x)
+        for h in hooks:
+            h.remove()
+        for i, conv in enumerate(det.m):
+            f = feats[i]                                               # (B, C, ny, nx) Detect input of this level
+            C = f.shape[1]
+            f = f.permute(1, 0, 2, 3).reshape(C, -1)                   # (C, B * ny * nx)
+            fbar = f.mean(1)
+            W = conv.weight.data.view(det.na, det.no, C)
+            b = conv.bias.data.view(det.na, det.no)
+            for a in range(det.na):
+                w0, b0 = W[a, 4].double(), float(b[a, 4])
+                # the row is made orthogonal to the mean feature vector (its constant part moves into the bias), so that
+                # amplifying it amplifies the input-dependent part only and the fp16 file holds O(1) numbers
+                b1 = b0 + float(w0 @ fbar)
+                w1 = w0 - (w0 @ fbar) / (fbar @ fbar) * fbar
+                amp = logit_std / float((w1 @ f).std())
+                w2 = (amp * w1).half().double()                        # what the fp16 checkpoint will hold
+                obj_logit = w2 @ f + b1
+                cls = torch.sigmoid(W[a, 5:].double() @ f + b[a, 5:].double()[:, None]).max(0)[0]
+                # the objectness logit an anchor needs for obj * cls == score_thr
+                need = torch.log((score_thr / cls) / (1 - score_thr / cls).clamp(min=1e-9))
+                margin = torch.sort(obj_logit - need, descending=True)[0]            # > 0 <=> above the threshold
+                lo, hi = per_plane
+                best = None
+                for k in range(lo, hi + 1):                                          # threshold between the k-th and the next
+                    b2 = float(torch.tensor(b1 - 0.5 * float(margin[k - 1] + margin[k])).half())     # fp16-representable
+                    m = margin + (b2 - b1)
+                    if not (m[k - 1] > 0 > m[k]):
+                        continue
+                    clear = float(min(m[k - 1], -m[k]))
+                    if best is None or clear > best[0]:
+                        best = (clear, b2)
+                assert best is not None
+                W[a, 4] = w2.float()
+                b[a, 4] = best[1]
+    with torch.no_grad():
+        p = model(x)
+    score = (p[..., 4:5] * p[..., 5:]).max(-1)[0]
+    return [int(v) for v in (score > score_thr).sum(1)]
+
+
 def save_checkpoint(model, path):
     """Same container as yolov5's strip_optimizer leaves behind: fp16 module pickled whole."""
     import copy

@@ -88,6 +88,40 @@ def test_preprocess_letterbox_resize_bit_exact(n6, shape):
     np.testing.assert_array_equal(got, PU.bf16_round_np(x.numpy()))
 
 
+@pytest.mark.parametrize('shape', [(256, 191), (191, 256), (256, 130), (130, 256), (256, 256), (255, 256)])
+def test_preprocess_streaming_copy_kernel_bit_exact(n6, shape, monkeypatch):
+    """[r5] batches without resampling (long side already at the network size) take the streaming-copy letterbox kernel
+    (aligned dword loads + a u8 -> storage-type table in LDS + 16-byte stores): bit-exact against the oracle's letterbox
+    (reference pytorch_detector.py:1104-1109, :1283-1306) for row lengths that are not multiples of four bytes (every row
+    starts at another alignment), padding on the left / right / top / bottom, device pointers at odd addresses, and the
+    same bits as the general kernel (MDHIP_LETTERBOX_GENERAL=1)."""
+    from megadetector_amd.postprocess import letterbox_geometry
+    W, ctx = n6
+    g = letterbox_geometry(shape, new_shape=256, stride=64)
+    assert (g['new_unpad'][1], g['new_unpad'][0]) == shape          # no resampling
+    imgs = PU.random_images(3, shape[0], shape[1], seed=shape[0] + 7 * shape[1])
+    geoms = [(shape[0], shape[1], shape[0], shape[1], g['top'], g['left'])] * 3
+    h, w = g['out_hw']
+    x, _ = PU.oracle_input(imgs, 256, 64)
+    assert tuple(x.shape[2:]) == (h, w)
+    want = PU.bf16_round_np(x.numpy())
+    ctx.preprocess(imgs, geoms, h, w)                                # host arrays: staged at aligned addresses
+    np.testing.assert_array_equal(ctx.read_input(3, h, w), want)
+    # device-resident sources at odd addresses (a view one / two / three bytes into a buffer)
+    n_bytes = shape[0] * shape[1] * 3
+    bufs = [torch.zeros(n_bytes + 8, dtype=torch.uint8, device='cuda') for _ in range(3)]
+    ptrs = []
+    for k, (b, im) in enumerate(zip(bufs, imgs)):
+        b[k + 1:k + 1 + n_bytes] = torch.from_numpy(im.reshape(-1)).cuda()
+        ptrs.append(int(b.data_ptr()) + k + 1)
+    torch.cuda.synchronize()
+    ctx.preprocess(ptrs, geoms, h, w)
+    np.testing.assert_array_equal(ctx.read_input(3, h, w), want)
+    monkeypatch.setenv('MDHIP_LETTERBOX_GENERAL', '1')
+    ctx.preprocess(ptrs, geoms, h, w)
+    np.testing.assert_array_equal(ctx.read_input(3, h, w), want)
+
+
 # ---------------------------------------------------------------------------------------
 # conv stack: layer by layer against the bf16-emulating oracle
 # ---------------------------------------------------------------------------------------

@@ -19,7 +19,11 @@ WORKLOADS = [                      # (dtype, batch, letterboxed H, W): bench.py'
     ('bf16', 32, 1280, 1280),      # BASELINE configs[1]
     ('bf16', 32, 768, 1280),       # configs[3]: 1080x1920 video frames
     ('bf16', 32, 960, 1280),       # SURVEY 8(d) real-shape: 1536x2048
+    ('bf16', 32, 896, 1280),       # 3:2 frames: 1600x2400
     ('fp16', 32, 1280, 1280),      # the detector's default storage type
+    ('fp16', 32, 768, 1280),
+    ('fp16', 32, 960, 1280),
+    ('fp16', 32, 896, 1280),
     ('fp8', 64, 1280, 1280),       # configs[4]
 ]
 
