@@ -617,7 +617,7 @@ def main():
                 'traffic': traffic, 'traffic_source': traffic_source,
                 'algorithmic_bytes_per_step': algorithmic_bytes,
                 'traffic_over_algorithmic': None if not traffic else round(traffic / algorithmic_bytes, 3),
-                'kernel': 'conv stack of one step = {} conv launches (conv_igemm_kernel / conv_v2_kernel / conv_v4_kernel / '
+                'kernel': 'conv stack of one step = {} conv launches (conv_igemm_kernel / conv_v2_kernel / conv_v7_kernel / '
                           'conv_v5_kernel / conv_v5s_kernel / conv_stem_kernel / conv_f8_kernel instantiations), HIP events on the launch stream around '
                           'mdhip_forward in the timed region, mean of {} steps'.format(len(conv), len(fwd_ms_live)),
                 'flops_per_step': conv_flops, 'kernel_ms_per_step': round(fwd_ms, 3),

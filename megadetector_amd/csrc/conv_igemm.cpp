@@ -493,7 +493,8 @@ struct Family {
 };
 const Family g_fams[] = {
     {conv2_num_cfgs, conv2_cfg, conv2_supports_l, conv2_launch, conv2_init, true, -1, false, true},
-    {conv4_num_cfgs, conv4_cfg, conv4_supports, conv4_launch, conv4_init, false, -201, false, false},
+    // (conv_v4.cpp -- the row-patch direct convolution of round 1, conv_v5's predecessor and the origin of the (group, r, s, c)
+    // weight packing -- left the build in round 5: no table entry had selected it since round 3)
     {conv5_num_cfgs, conv5_cfg, conv5_supports, conv5_launch, conv5_init, false, -301, false, false},
     {conv6_num_cfgs, conv6_cfg, conv6_supports, conv6_launch, conv6_init, true, -401, false, false},     // the stem kernel: same K order
     {conv8_num_cfgs, conv8_cfg, conv8_supports, conv8_launch, conv8_init, false, -801, true, false},

@@ -150,7 +150,7 @@ struct ConvArgs {
     int act;                // 1 = SiLU
     int out_f32;            // 1 = fp32 output, no rounding (Detect logits)
     int tiles_n, tiles_m, tiles_per_xcd, m_streams;   // filled by conv_launch
-    // row-patch direct convolution (conv_v4.cpp): weights packed [n_rows][groups*9*64], k = (cg, r, s, c % 64)
+    // second packing (introduced by the row-patch kernel of round 1; read by conv_v5 / conv_v5s / conv_v5c / conv_v7 / conv_f8): weights packed [n_rows][groups*9*64], k = (cg, r, s, c % 64)
     const uint16_t* wgt4;   // nullptr when the op has no such packing
     int k_pad4, groups;
     // conv_v5.cpp, layers whose last channel group is at most half full (C_in mod 64 in 8 .. 32: the 160- and 480-channel
@@ -230,9 +230,8 @@ struct ConvCfg {
 
 // The conv API exists once per storage type (see MDHIP_ST above):
 //   conv_*  : dispatch over all kernels (conv_igemm.cpp); ids [0, conv_num_v1_cfgs()) run conv_igemm.cpp's
-//             kernel (every shape), then conv_v2.cpp's, conv_v4.cpp's, conv_v5.cpp's, conv_v6.cpp's
+//             kernel (every shape), then conv_v2.cpp's, conv_v5.cpp's, conv_v6.cpp's
 //   conv2_* : second-generation main loop (conv_v2.cpp); local ids, reached through conv_launch
-//   conv4_* : row-patch direct convolution for 3x3 / stride 1 (conv_v4.cpp)
 //   conv5_* : 3x3 / stride 1 with row-segment reuse across the taps of a kernel row (conv_v5.cpp); its configurations
 //             for small launches (conv5s_*, conv_v5s.cpp) are listed behind its own
 //   conv6_* : the stem (3x3 over 16-channel space-to-depth pixels, N = 80) with its weights in registers (conv_v6.cpp)
@@ -256,11 +255,6 @@ struct ConvCfg {
     bool conv2_is_pointwise(const ConvArgs& a); \
     hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s); \
     hipError_t conv2_init(); \
-    int conv4_num_cfgs(); \
-    const ConvCfg& conv4_cfg(int i); \
-    bool conv4_supports(int cfg, const ConvArgs& a); \
-    hipError_t conv4_launch(int cfg, const ConvArgs& a, hipStream_t s); \
-    hipError_t conv4_init(); \
     int conv5_num_cfgs(); \
     const ConvCfg& conv5_cfg(int i); \
     bool conv5_supports(int cfg, const ConvArgs& a); \

@@ -18,6 +18,13 @@ Modes:
                 consumers read e4m3 activations against their 16-bit weights (the most favourable variant: weights
                 not quantised).  Tensors that feed a residual add stay in bf16.
   fp8-all-w     the same with the consumers' weights in e4m3 too (per output channel), which is what an e4m3 MFMA needs
+  [r5] the same four under MX BLOCK SCALES (OCP microscaling: every 32 consecutive channels of a pixel share one E8M0
+  scale 2^(floor(log2 amax) - 8), computed by the producer from its fp32 values -- the operand `v_mfma_scale_f32_16x16x128
+  _f8f6f4` takes per 32 k and that conv_f8.cpp feeds with unit scales today; no calibration, no static ranges):
+  mx            today's contract with the hidden tensors block-scaled (3x3 weights per output channel as today)
+  mx-w          + the 3x3 weights block-scaled along K too (32 input channels of one tap share a scale)
+  mx-all        + the 71 tensors that only 1x1 / stride-2 convs read, block-scaled e4m3; consumers' weights 16-bit
+  mx-all-w      + the consumers' weights block-scaled e4m3 (what an all-e4m3 MFMA path needs)
 
 Usage: python tests/fp8_all_storage_study.py [--size 640] > profiles/rN_fp8_all_storage_study.txt
 """
@@ -43,11 +50,34 @@ def e4m3(t, scale):
     return (t * (torch.tensor(1.0, dtype=torch.float32) / s)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * s
 
 
+def mx_e4m3(t, dim=1, block=32):
+    """OCP MX e4m3: blocks of `block` consecutive elements along `dim` share the power-of-two scale
+    2^(floor(log2(max|x|)) - 8) (8 = emax of e4m3: the block's largest element lands in [256, 512) -> saturates at 448 like
+    the spec's conversion); elements are rounded to e4m3 (RNE) after the division.  Returns the dequantised tensor."""
+    t = t.movedim(dim, -1)
+    shp = t.shape
+    c = shp[-1]
+    pad = (-c) % block
+    if pad:
+        t = F.pad(t, (0, pad))
+    b = t.reshape(*t.shape[:-1], -1, block)
+    amax = b.abs().amax(-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp(min=2.0 ** -120))) - 8.0
+    scale = torch.pow(torch.tensor(2.0, dtype=torch.float32), e.clamp(-127.0, 127.0))
+    q = (b / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * scale
+    q = q.reshape(*t.shape)[..., :c].reshape(shp)
+    return q.movedim(-1, dim)
+
+
 class StudyForward(Y.Forward):
     """oracle forward with e4m3 storage of a named set of conv outputs (the names are decided by `wanted`)"""
 
     def __init__(self, yaml, weights, mode, scales=None, hidden_scales=None):
         super().__init__(yaml, weights, emulate_bf16='fp8' if mode != 'bf16' else True, fp8_scales=hidden_scales)
+        self.mx = mode.startswith('mx')
+        self.mx_w3 = mode in ('mx-w', 'mx-all-w')          # bottleneck 3x3 weights block-scaled along K
+        if self.mx:
+            mode = {'mx': 'fp8', 'mx-w': 'fp8', 'mx-all': 'fp8-all', 'mx-all-w': 'fp8-all-w'}[mode]
         self.mode = mode
         self.scales = scales                 # None: record ranges (calibration pass)
         self.amax = {}
@@ -85,6 +115,8 @@ class StudyForward(Y.Forward):
             amax = w32.abs().amax(dim=(1, 2, 3))
             s_w = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)).view(-1, 1, 1, 1)
             w = (w32 / s_w).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * s_w
+            if self.mx:
+                w = mx_e4m3(w32, dim=1)
         y = F.conv2d(x, w, self.w[name + '.bias'], stride=s, padding=p)
         if act:
             y = F.silu(y)
@@ -95,6 +127,8 @@ class StudyForward(Y.Forward):
             if self.scales is None:
                 self.amax[name] = max(self.amax.get(name, 0.0), float(y.abs().max()))
                 y = self._round(y)
+            elif self.mx:
+                y = mx_e4m3(y, dim=1)
             else:
                 y = e4m3(y, self.scales[name])
             return y
@@ -106,12 +140,30 @@ class StudyForward(Y.Forward):
             key = (int(pre.split('.')[1]), j)
             self.hidden_amax[key] = max(self.hidden_amax.get(key, 0.0), float(t.abs().max()))
             return self._conv(t, '{}.m.{}.cv2.conv'.format(pre, j), 3, 1, 1, residual=y1 if shortcut else None)
-        y = super()._bottleneck_fp8(y1, pre, j, scale, shortcut)
+        if self.mx:
+            # hidden tensor block-scaled from the 1x1's fp32 epilogue values; 3x3 weights per output channel (today's
+            # packing) or block-scaled along K; fp32 accumulation; the scales ride with the operands (v_mfma_scale)
+            n1, n2 = '{}.m.{}.cv1.conv'.format(pre, j), '{}.m.{}.cv2.conv'.format(pre, j)
+            t = F.silu(F.conv2d(y1, self.w[n1 + '.weight'], self.w[n1 + '.bias']))
+            q = mx_e4m3(t, dim=1)
+            w = self.w32[n2 + '.weight']
+            if self.mx_w3:
+                wq = mx_e4m3(w, dim=1)
+            else:
+                amax = w.abs().amax(dim=(1, 2, 3))
+                s_w = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)).view(-1, 1, 1, 1)
+                wq = (w / s_w).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * s_w
+            y = F.silu(F.conv2d(q, wq, self.w[n2 + '.bias'], stride=1, padding=1))
+            if shortcut:
+                y = y1 + y
+            y = self._round(y)
+        else:
+            y = super()._bottleneck_fp8(y1, pre, j, scale, shortcut)
         name = '{}.m.{}.cv2.conv'.format(pre, j)
         if self.mode.startswith('fp8-all') and self.scales is not None and self.wanted(name):
             # (super() rounded to bf16 first: one extra rounding on these few tensors, far below the e4m3 step)
             self.qnames.add(name)
-            y = e4m3(y, self.scales[name])
+            y = mx_e4m3(y, dim=1) if self.mx else e4m3(y, self.scales[name])
         return y
 
     def _c3(self, x, L):
@@ -156,8 +208,9 @@ def main():
     print('# calibrated on 2 other images: {} hidden tensors (today\'s contract), {} further tensors for "all"'.format(len(hidden), len(scales)))
 
     print('{:10s} {:>12s} {:>16s} {:>16s} {:>12s}'.format('mode', 'max|dconf|', 'max|dconf| >0.1', 'max|dscore|>.005', 'box rel max'))
-    for mode in ('bf16', 'fp8', 'fp8-all', 'fp8-all-w'):
+    for mode in ('bf16', 'fp8', 'fp8-all', 'fp8-all-w', 'mx', 'mx-w', 'mx-all', 'mx-all-w'):
         fw = StudyForward(W.yaml, state, mode, scales=scales, hidden_scales=hidden if mode != 'bf16' else None)
+        fw.q_weights = fw.mode == 'fp8-all-w'
         with torch.no_grad():
             got = fw(x).numpy()
         d = np.abs(got[..., 4:] - ref[..., 4:])

@@ -136,7 +136,6 @@ int main(int argc, char** argv) {
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "all")) { for (int j = 0; j < conv_num_cfgs(); ++j) cfgs.push_back(j); continue; }
         if (argv[i][0] == 'p') { cfgs.push_back(-1 - atoi(argv[i] + 1)); continue; }   // p0, p1: instrumented v2 variants
-        if (argv[i][0] == 'r') { cfgs.push_back(-201 - atoi(argv[i] + 1)); continue; } // r0, r1: v4 developer variants
         if (argv[i][0] == 't') { cfgs.push_back(-301 - atoi(argv[i] + 1)); continue; } // t0..: v5 developer variants
         if (argv[i][0] == 'u') { cfgs.push_back(-401 - atoi(argv[i] + 1)); continue; } // u0..: v6 developer variants
         if (argv[i][0] == 'f') { cfgs.push_back(-801 - atoi(argv[i] + 1)); continue; } // f0..: fp8 developer variants
@@ -330,7 +329,7 @@ int main(int argc, char** argv) {
             if (ms < best) best = ms;
         }
         printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
-               cfg <= -801 ? conv8_cfg(conv8_num_cfgs() - 801 - cfg).name : cfg <= -401 ? conv6_cfg(conv6_num_cfgs() - 401 - cfg).name : cfg <= -301 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : cfg <= -201 ? conv4_cfg(conv4_num_cfgs() - 201 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
+               cfg <= -801 ? conv8_cfg(conv8_num_cfgs() - 801 - cfg).name : cfg <= -401 ? conv6_cfg(conv6_num_cfgs() - 401 - cfg).name : cfg <= -301 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
                bad ? "  <-- MISMATCH" : "");
         if (cfg < 0) {
             // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
