@@ -485,11 +485,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if one_gpu:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+        import datetime
+        # the path has no data-path collective: the process group only carries the barriers around the timed
+        # region and the MAX over ranks.  RCCL by default (one rank per GPU); MDHIP_BENCH_BACKEND=gloo keeps that control
+        # plane on the host if RCCL cannot start on a box (and is what the one-GPU test hook uses)
+        gloo = one_gpu or os.environ.get('MDHIP_BENCH_BACKEND', 'nccl') == 'gloo'
+        if gloo:
+            dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world,
+            dist.init_process_group('nccl', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300),
                                     device_id=torch.device('cuda', local_rank))
+        one_gpu = gloo                                          # (from here on: "control tensors live on the host")
 
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.postprocess import format_detections

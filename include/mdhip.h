@@ -164,8 +164,11 @@ int mdhip_nms(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_
  * complete and returns pointers into it ([n][max_det][6] floats, [n] counts), valid until the
  * slot is enqueued again. 
  * Every forward writes the other of two prediction buffers, so mdhip_nms_enqueue may run on another stream
- * than the forward of the next batch (order it behind its own forward with an event); it must have completed
- * before the forward after next starts. */
+ * than the forward of the next batch.  Ordering contract: the CALLER orders the enqueue behind its own forward (an
+ * event recorded after mdhip_forward, waited for on the NMS stream); the LIBRARY orders the forward after next behind
+ * the enqueue -- mdhip_nms_enqueue records an event for the prediction buffer it reads, and the forward that is about
+ * to overwrite that buffer (mdhip_forward / mdhip_forward_tta, any stream) waits for it.  The scratch buffers of the
+ * NMS kernels are shared: keep all mdhip_nms* calls of one context on ONE stream. */
 #define MDHIP_NMS_SLOTS 4
 int mdhip_nms_enqueue(mdhip_ctx* ctx, int n, float conf_thres, float iou_thres, int max_det,
                       int slot, void* hip_stream);

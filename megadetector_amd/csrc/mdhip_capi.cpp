@@ -1333,17 +1333,19 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
     }
     // the forward that still reads the input tensor (its stem) comes first, whatever stream it runs on
     if (ctx->input_free_valid) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->input_free, 0));
-    // geometry goes through a 4-deep pinned ring so that the call never blocks on the stream
-    const int slot = ctx->geom_slot;
-    ctx->geom_slot = (slot + 1) & 3;
-    HIP_TRY(ctx, hipEventSynchronize(ctx->geom_ev[slot]));          // slot's previous copy has completed
-    LetterboxDev* gh = ctx->geom_host + (size_t)slot * ctx->max_batch;
-    memcpy(gh, g.data(), n * sizeof(LetterboxDev));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena + ctx->geom_off, gh, n * sizeof(LetterboxDev), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipEventRecord(ctx->geom_ev[slot], s));
     bool no_resampling = getenv("MDHIP_LETTERBOX_GENERAL") == nullptr;
     for (int i = 0; i < n; ++i) no_resampling = no_resampling && g[i].resized_h == g[i].src_h && g[i].resized_w == g[i].src_w;
-    HIP_TRY(ctx, launch_letterbox_s2d((const LetterboxDev*)(ctx->arena + ctx->geom_off), n, out_h, out_w,
+    if (!letterbox_geometry_travels_inline(n, out_w, no_resampling)) {
+        // geometry goes through a 4-deep pinned ring so that the call never blocks on the stream
+        const int slot = ctx->geom_slot;
+        ctx->geom_slot = (slot + 1) & 3;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->geom_ev[slot]));          // slot's previous copy has completed
+        LetterboxDev* gh = ctx->geom_host + (size_t)slot * ctx->max_batch;
+        memcpy(gh, g.data(), n * sizeof(LetterboxDev));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->arena + ctx->geom_off, gh, n * sizeof(LetterboxDev), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipEventRecord(ctx->geom_ev[slot], s));
+    }
+    HIP_TRY(ctx, launch_letterbox_s2d((const LetterboxDev*)(ctx->arena + ctx->geom_off), g.data(), n, out_h, out_w,
                                       (uint16_t*)(ctx->arena + ctx->input.off), ctx->dtype == MDHIP_DTYPE_FP16, no_resampling, s));
     ctx->last_n = n;
     ctx->last_h = out_h;

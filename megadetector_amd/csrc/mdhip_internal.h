@@ -303,7 +303,10 @@ struct LetterboxDev {     // device copy of mdhip_letterbox + source pointer
 };
 // u8 HWC -> space-to-depth bf16 [n][out_h/2][out_w/2][16] (12 real channels: (dy,dx,c)), /255
 // (no_resampling: every image of the batch has resized == source size -> the streaming-copy kernel)
-hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, int n, int out_h, int out_w,
+// geom_host: the same geometry in host memory; when letterbox_geometry_travels_inline(...) it is passed in the kernel
+// arguments and geom_dev is not read (the caller skips the upload)
+bool letterbox_geometry_travels_inline(int n, int out_w, bool no_resampling);
+hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, const LetterboxDev* geom_host, int n, int out_h, int out_w,
                                 uint16_t* out, int f16, bool no_resampling, hipStream_t s);
 // SPPF: three chained 5x5/s1/p2 max pools of slice 0 written to slices 1..3 of the same buffer
 hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, int k, int f16, hipStream_t s);

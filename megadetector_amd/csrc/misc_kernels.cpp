@@ -183,8 +183,15 @@ letterbox_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w
 // Measured (batch 32, 1280x1280, live events incl. the geometry upload): 0.223 -> 0.154 ms (3.07 TB/s).  Four s2d rows per
 // workgroup with the next row's dwords prefetched into registers: 0.170 ms -- slower (a quarter of the workgroups, 16 more
 // registers); not kept.
+// Geometry of up to kLbInline images travels in the kernel arguments (scalar loads from the kernarg segment): no H2D copy
+// in front of the launch (the 1.3 KB upload cost 10 - 15 us of stream time per batch); larger batches read `ptr`.
+constexpr int kLbInline = 32;
+struct LetterboxGeom {
+    const LetterboxDev* ptr;
+    LetterboxDev inl[kLbInline];
+};
 __global__ void __launch_bounds__(256)
-letterbox_copy_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int out_w,
+letterbox_copy_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w,
                           uint16_t* __restrict__ out, int f16) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lb_lds[];
     uint16_t* lut = (uint16_t*)lb_lds;                          // 256 entries
@@ -192,7 +199,7 @@ letterbox_copy_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int 
     const int img = blockIdx.y, Y = blockIdx.x, t = threadIdx.x;
     const int W2 = out_w >> 1, H2 = out_h >> 1;
     const int row_dw = (out_w * 3) >> 1;                        // dwords per staged row (out_w is a multiple of 4)
-    const LetterboxDev g = geom[img];
+    const LetterboxDev g = geom.ptr ? geom.ptr[img] : geom.inl[img];
     lut[t] = f32_to_st((float)t / 255.0f, f16);
     __syncthreads();
     const uint32_t pad1 = lut[114], pad2 = pad1 | (pad1 << 16);
@@ -252,12 +259,26 @@ letterbox_copy_s2d_kernel(const LetterboxDev* __restrict__ geom, int out_h, int 
     }
 }
 
-hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, int n, int out_h, int out_w,
+static bool lb_copy_kernel_ok(int out_w, bool no_resampling) {
+    return no_resampling && (out_w % 4) == 0 && 512 + (size_t)out_w * 12 <= 65536;
+}
+bool letterbox_geometry_travels_inline(int n, int out_w, bool no_resampling) {
+    return lb_copy_kernel_ok(out_w, no_resampling) && n <= kLbInline;
+}
+
+hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, const LetterboxDev* geom_host, int n, int out_h, int out_w,
                                 uint16_t* out, int f16, bool no_resampling, hipStream_t s) {
     const int W2 = out_w / 2, H2 = out_h / 2;
     const size_t lds = 512 + (size_t)out_w * 12;
-    if (no_resampling && (out_w % 4) == 0 && lds <= 65536) {
-        hipLaunchKernelGGL(letterbox_copy_s2d_kernel, dim3(H2, n), dim3(256), lds, s, geom_dev, out_h, out_w, out, f16);
+    if (lb_copy_kernel_ok(out_w, no_resampling)) {
+        LetterboxGeom geom;
+        geom.ptr = geom_dev;
+        if (letterbox_geometry_travels_inline(n, out_w, no_resampling)) {
+            geom.ptr = nullptr;
+            for (int i = 0; i < n; ++i) geom.inl[i] = geom_host[i];
+            for (int i = n; i < kLbInline; ++i) geom.inl[i] = LetterboxDev{nullptr, 0, 0, 0, 0, 0, 0, 0};
+        }
+        hipLaunchKernelGGL(letterbox_copy_s2d_kernel, dim3(H2, n), dim3(256), lds, s, geom, out_h, out_w, out, f16);
         return hipGetLastError();
     }
     dim3 grid((W2 + 255) / 256, H2, n);
