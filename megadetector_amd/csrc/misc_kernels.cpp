@@ -223,27 +223,18 @@ letterbox_copy_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w,
                     const uint32_t w0 = al[0];
                     const uint32_t w1 = sh ? al[1] : 0u;
                     v = __builtin_amdgcn_alignbyte(w1, w0, sh);
-                } else {
+                } else {                                        // the <= 2 groups of a row that straddle an image edge
                     v = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int ok = o + k;
-                        const uint32_t b = ((unsigned)ok < (unsigned)row_bytes) ? rb[ok] : 256u;
-                        v |= (b & 0x1ffu) << (9 * k);           // 9-bit fields: 256 marks a padding byte
+                        v |= (((unsigned)ok < (unsigned)row_bytes) ? (uint32_t)rb[ok] : 114u) << (8 * k);   // padding byte = 114
                     }
-                    // (edge groups only: unpack below through the same table, padding -> table[114])
-                    const uint32_t b0 = v & 0x1ff, b1 = (v >> 9) & 0x1ff, b2 = (v >> 18) & 0x1ff, b3 = (v >> 27) & 0x1ff;
-                    lo16 = (b0 > 255 ? pad1 : lut[b0]) | ((b1 > 255 ? pad1 : (uint32_t)lut[b1]) << 16);
-                    hi16 = (b2 > 255 ? pad1 : lut[b2]) | ((b3 > 255 ? pad1 : (uint32_t)lut[b3]) << 16);
-                    dst[2 * gi] = lo16;
-                    dst[2 * gi + 1] = hi16;
-                    continue;
                 }
                 lo16 = lut[v & 0xff] | ((uint32_t)lut[(v >> 8) & 0xff] << 16);
                 hi16 = lut[(v >> 16) & 0xff] | ((uint32_t)lut[v >> 24] << 16);
             }
-            dst[2 * gi] = lo16;
-            dst[2 * gi + 1] = hi16;
+            *(uint2*)(dst + 2 * gi) = make_uint2(lo16, hi16);
         }
     }
     __syncthreads();
