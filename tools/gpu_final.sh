@@ -1,11 +1,11 @@
 #!/bin/bash
 # Final measurement session of a round (everything committed under profiles/r<N>_* comes from gpurun_out/final<N>/ of ONE box):
-# bench tile lists, the GPU test suite and smoke, bench lines (headline with extra_configs, per-op profile, fp8, fp16, small
+# bench tile lists, the GPU test suite (with the printed parity numbers) and smoke, bench lines (headline with extra_configs, per-op profile, fp8, fp16, small
 # batches, real shapes, PCIe-inclusive, NMS stream A/B), rocprofv3 kernel trace, the counter passes (separate runs, counters
 # only).  usage on the GPU box:  ROUND=4 bash tools/gpu_final.sh      (tables are NOT re-tuned here: tools/retune_all.sh)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-R=${ROUND:-4}
+R=${ROUND:-5}
 O=gpurun_out/final$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -16,7 +16,9 @@ stamp() { echo "$1 at $(( $(date +%s) - T0 )) s" >> $O/timing.log; }
 timeout 300 python tools/dump_bench_tiles.py > $O/dump_tiles.log 2>&1; cp tests/golden/bench_tiles.json $O/bench_tiles.json
 stamp "tile lists"
 # ---- tests and smoke ----
-timeout 1200 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q -rP --timeout 900 > $O/pytest_gpu_full.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu_full.log
+# (the committed log: the progress lines, the parity numbers the tests print, the summary)
+grep -E "^\.|passed|failed|pytest exit|x6 checkpoint|sparse x6|worst|predictions:|fp8 x6|conf|tile configurations" $O/pytest_gpu_full.log | cut -c1-600 > $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
 stamp "tests"
 # ---- bench lines ----
@@ -43,6 +45,9 @@ stamp "pmc"
 left && timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs --src 1536x2048 > $O/bench_real43.log 2>&1
 left && timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs --src 1080x1920 > $O/bench_video_1080p.log 2>&1
 left && timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs --src 1600x2400 > $O/bench_real32.log 2>&1
+for s in 1080x1920 1536x2048 1600x2400; do
+  left && timeout 200 python bench.py --dtype fp16 --src $s --steps 30 --warmup 5 --no-cpu-baseline --no-extra-configs --lean > $O/bench_fp16_$s.log 2>&1
+done
 for b in 1 2 4 8 16; do
   left && timeout 200 python bench.py --batch $b --steps 60 --warmup 10 --no-cpu-baseline --lean > $O/bench_b$b.log 2>&1
 done
@@ -53,6 +58,9 @@ ls -laR $O > $O/ls.log
 # ---- the multi-rank code path of bench.py on this one GPU (gloo test hook), the end-to-end feed on JPEG files ----
 left && MDHIP_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 2 --batch 8 --steps 30 --warmup 5 > $O/bench_2rank_one_gpu_gloo.log 2>&1
+# the self-launching form (`python bench.py --gpus 2`, no launcher) and a pinned single-GPU run (placement.pin_worker(force))
+left && MDHIP_BENCH_ONE_GPU=1 timeout 300 python bench.py --gpus 2 --batch 8 --steps 30 --warmup 5 > $O/bench_selflaunch_2rank.log 2> $O/bench_selflaunch_2rank.err
+left && timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs --pin-cpus > $O/bench_pinned.log 2> $O/bench_pinned.err
 left && timeout 400 python tools/e2e_feed_bench.py --n 4096 --workers 16,24 --out $O/e2e_feed.json > $O/e2e_feed.log 2>&1
 # the NUMA placement code on this box's topology (8 GPUs asked for: what the planner does with the GPUs it cannot see)
 left && python -c "
