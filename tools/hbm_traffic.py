@@ -7,7 +7,7 @@ MI355X_MICROARCH.md 'rocprofv3 PMC slots').
 usage: hbm_traffic.py <fetch_pass_dir> <write_pass_dir> <key> <out.json>
 
 Both passes ran `bench.py --lean --steps K --warmup W`, i.e. exactly W+K identical steps; a step has
-exactly one letterbox_s2d_kernel dispatch, which is how the steps are counted.  Units and the gfx950
+exactly one letterbox_s2d_kernel (or letterbox_copy_s2d_kernel) dispatch, which is how the steps are counted.  Units and the gfx950
 correction follow the guide's HBM section: the counters are in KiB; FETCH_SIZE tallies the 128-byte
 requests of a wide coalesced stream at 64 bytes, i.e. reports half of the bytes such streams move, so
 it is doubled; WRITE_SIZE is taken as reported (uncalibrated per the guide).
@@ -30,7 +30,7 @@ def load(pass_dir, counter):
                 continue
             name = r['Kernel_Name'].split('(')[0]
             per_kernel[name] += float(r['Counter_Value'])
-            if 'letterbox_s2d' in name and r['Dispatch_Id'] not in seen:
+            if 'letterbox_' in name and 's2d' in name and r['Dispatch_Id'] not in seen:
                 seen.add(r['Dispatch_Id'])
                 steps += 1
     return per_kernel, steps
