@@ -35,7 +35,6 @@
 // epilogue goes through buffer instructions with one 32-bit offset per lane (DESIGN.md section 5 [r3b]).
 
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 #include "mdhip_internal.h"
@@ -70,11 +69,6 @@ constexpr int v5_blocks_per_cu(int bm, int bn, int nw) {
 constexpr bool v5_is_lean(int bm, int bn, int wm, int wn) { return bm / wm == 80 && bn / wn == 80; }
 // aligned mode (conv_v5_kernel AL): zero rows at ZERO_OFF + i * 2048, i = 1..4, behind the zero row / bias area
 constexpr int v5_al_extra_lds = 4 * 2048;
-// residual staging (conv_v5_kernel RSTG): per wave and staged pixel row three 1 KiB pieces (column pair 0, pair 1, last column)
-constexpr int v5_stg_row_bytes = 3 * 1024;
-constexpr int v5_stg_extra_lds(int nw) { return nw * v5_stg_row_bytes; }
-// (the 320x160 tile: six free loader slots in a tile's last step, a run buffer that holds a staged row of all eight waves)
-constexpr bool v5_can_stage(int bm, int bn, int wm, int wn) { return bm / wm == 80 && bn / wn == 80 && bm == 320 && wm * wn == 8; }
 constexpr int v5_waves_per_simd(int bm, int bn, int nw) {
     int w = v5_blocks_per_cu(bm, bn, nw) * nw / 4;
     return w < 1 ? 1 : w;
@@ -97,13 +91,7 @@ constexpr int v5_waves_per_simd(int bm, int bn, int nw) {
 // 9-bit mask per lane and fragment: one address register for fragments 1..3 (fragment i at the immediate offset i * 2048, a
 // row of zeros at each of those offsets for a wave whose tap falls above / below the image), two for the edge fragments;
 // 5-6 VALU instructions a step instead of ~36 (a select per fragment, the shift arithmetic, the k-half XOR per fragment).
-// RSTG ("residual staging", aligned 8-wave tiles with a residual operand only) [r5]: the residual rows of the first two
-// pixel rows of the epilogue are requested by LDS-DMA in the LAST step of the tile -- row 1 into LDS the tile never uses
-// (behind the aligned mode's zero rows), row 0 into the run buffer that step has just finished reading -- each wave its own
-// 80 x 80 region in "register image" order (lane l's 16 bytes at piece + 16 l: what the buffer loads of the register path
-// return), so the epilogue starts on data that is already on chip while the rows 2 .. 4 travel through registers as before.
-// Without it every pixel row of the epilogue waits out most of a memory round trip with two rows in flight (§5 [r4]).
-template <int BM, int BN, int WM, int WN, int PROF = 0, int TAIL = -1, bool AL = false, bool RSTG = false>
+template <int BM, int BN, int WM, int WN, int PROF = 0, int TAIL = -1, bool AL = false>
 __global__ void __launch_bounds__(WM * WN * 64, v5_waves_per_simd(BM, BN, WM * WN))
 conv_v5_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -117,9 +105,6 @@ conv_v5_kernel(const ConvArgs p) {
     constexpr int B_OFF = 2 * A_BUF;
     constexpr int ZERO_OFF = B_OFF + 2 * B_BYTES;
     static_assert(TM % 16 == 0 && TN % 16 == 0, "16x16 fragments");
-    static_assert(!RSTG || (AL && FM == 5 && FN == 5 && NW * v5_stg_row_bytes <= A_BUF), "residual staging: aligned 8-wave tiles");
-    // (RSTG) staged residual row 1: behind everything else the kernel keeps in LDS
-    [[maybe_unused]] constexpr int STG_FREE_OFF = v5_lds_bytes(BM, BN) + v5_al_extra_lds;
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lds_char* const smem = (lds_char*)smem_generic;
@@ -368,7 +353,7 @@ conv_v5_kernel(const ConvArgs p) {
 
     // ---- epilogue (bias staged in LDS, pixel-row order, packed SiLU, 16-byte buffer stores) ----------
     const int q4 = lane >> 4;
-    auto epilogue_t = [&](int tile_m, [[maybe_unused]] int stg_buf, auto has_res_t, auto out_f32_t, auto act_t) __attribute__((always_inline)) {
+    auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t, auto act_t) __attribute__((always_inline)) {
         // (x * r and the residual add stay two roundings -- as in every other kernel family, where a select on the
         // activation flag sits between them: the results of the network do not depend on which tile a layer got)
 #pragma clang fp contract(off)
@@ -417,6 +402,8 @@ conv_v5_kernel(const ConvArgs p) {
         auto read_bias = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
+                // (address from the opaque lane copy: formed from `lane` it is hoisted above the main loop, one register per column --
+                // the paired-tail instantiations spilled two of them and reloaded each behind an s_waitcnt vmcnt(0) in the epilogue [r5])
                 bv[j] = *(const __attribute__((address_space(3))) f32x4*)lds_at((unsigned)(ZERO_OFF + 256 + (wn * TN + j * 16) * 4) + (unsigned)lq * 16u);
         };
         if constexpr (!BIAS_PER_ROW) read_bias();
@@ -449,35 +436,13 @@ conv_v5_kernel(const ConvArgs p) {
                 rl = make_uint2(t[0], t[1]);
             }
         };
-        // (RSTG: rows 1 and 0 come from LDS -- requested in the tile's last step, see stage_res_piece -- and are finished first, in
-        // that order, while the rows 2 and 3 requested here are in flight; row 4 follows when row 2 is taken up.  Register
-        // slots: rows 2 / 3 / 4 -> 2 / 0 / 1, the staged rows pass through slot 1 before row 4 is requested into it.)
-        constexpr bool STG = RSTG && HAS_RES;
-        auto slot_of = [](int i) constexpr { return STG ? (i < 2 ? 1 : i % RS) : i % RS; };
-        if constexpr (STG) {
-            fetch_res_row(2, rpair[slot_of(2)], rlast[slot_of(2)]);
-            fetch_res_row(3, rpair[slot_of(3)], rlast[slot_of(3)]);
-            // everything older than those six loads -- the staged pieces among it -- has landed (loads complete in order)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else if constexpr (HAS_RES) {
+        if constexpr (HAS_RES) {
 #pragma unroll
             for (int a = 0; a < RA && a < FM; ++a) fetch_res_row(a, rpair[a % RS], rlast[a % RS]);
         }
 #pragma unroll
-        for (int t = 0; t < FM; ++t) {
-            const int i = STG ? (t == 0 ? 1 : (t == 1 ? 0 : t)) : t;
-            if constexpr (STG) {
-                if (i < 2) {
-                    const unsigned base = (i == 0 ? (unsigned)(stg_buf * A_BUF) : (unsigned)STG_FREE_OFF) +
-                                          (unsigned)(wave * v5_stg_row_bytes) + (unsigned)lane_e * 16u;
-#pragma unroll
-                    for (int jp = 0; jp < NPAIR; ++jp)
-                        rpair[slot_of(i)][jp] = *(const __attribute__((address_space(3))) uint4*)lds_at(base + (unsigned)(jp * 1024));
-                    rlast[slot_of(i)] = *(const __attribute__((address_space(3))) uint2*)lds_at(base + 2048u);
-                } else if (i + 2 < FM) {
-                    fetch_res_row(i + 2, rpair[slot_of(i + 2)], rlast[slot_of(i + 2)]);
-                }
-            } else if constexpr (HAS_RES) {
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (HAS_RES) {
                 if (i + RA < FM) fetch_res_row(i + RA, rpair[(i + RA) % RS], rlast[(i + RA) % RS]);
             }
             const int m = m0 + i * 16;
@@ -505,7 +470,7 @@ conv_v5_kernel(const ConvArgs p) {
                 };
 #pragma unroll
                 for (int jp = 0; jp < NPAIR; ++jp) {
-                    const uint4 d = rpair[slot_of(i)][jp];       // as stored: (t0[0], t1[0], t0[1], t1[1])
+                    const uint4 d = rpair[i % RS][jp];           // as stored: (t0[0], t1[0], t0[1], t1[1])
                     auto s0 = __builtin_amdgcn_permlane16_swap(d.x, d.z, false, false);
                     auto s1 = __builtin_amdgcn_permlane16_swap(d.y, d.w, false, false);
                     auto a0 = __builtin_amdgcn_permlane32_swap(s0[0], s0[1], false, false);     // (a0, b0)
@@ -514,7 +479,7 @@ conv_v5_kernel(const ConvArgs p) {
                     add4(2 * jp + 1, a0[1], a1[1]);
                 }
                 if (FN & 1) {
-                    add4(FN - 1, rlast[slot_of(i)].x, rlast[slot_of(i)].y);
+                    add4(FN - 1, rlast[i % RS].x, rlast[i % RS].y);
                 }
             }
             if constexpr ((PROF & 2) != 0) {
@@ -552,17 +517,16 @@ conv_v5_kernel(const ConvArgs p) {
     };
     // The 8-wave tiles are built for activated 16-bit outputs only (conv5_supports): two epilogues, no select per value.
     // The others take the activation flag at run time (std::false_type = "ask p.act").
-    // (stg_buf, RSTG: the run buffer the tile's last step finished reading -- where the staged residual row 0 lies)
-    auto epilogue = [&](int tile_m, int stg_buf) __attribute__((always_inline)) {
+    auto epilogue = [&](int tile_m) __attribute__((always_inline)) {
         if constexpr (LEAN) {
             // (s_setprio 2 on the first four waves for the epilogue -- so that one wave of a SIMD computes while the other waits
             // for the memory path -- was measured: no difference on any layer, profiles/r4_convbench_epilogue_prio.txt)
-            if (RSTG || p.res) epilogue_t(tile_m, stg_buf, std::true_type{}, std::false_type{}, std::true_type{});
-            else epilogue_t(tile_m, stg_buf, std::false_type{}, std::false_type{}, std::true_type{});
+            if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::true_type{});
+            else epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::true_type{});
         } else {
-            if (p.out_f32) epilogue_t(tile_m, stg_buf, std::false_type{}, std::true_type{}, std::false_type{});
-            else if (p.res) epilogue_t(tile_m, stg_buf, std::true_type{}, std::false_type{}, std::false_type{});
-            else epilogue_t(tile_m, stg_buf, std::false_type{}, std::false_type{}, std::false_type{});
+            if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{}, std::false_type{});
+            else if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::false_type{});
+            else epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::false_type{});
         }
     };
 
@@ -619,26 +583,6 @@ conv_v5_kernel(const ConvArgs p) {
     // DMA slots behind the MFMA chunks of a second half: the weight pieces of step + 2, then this step's share of the NEXT
     // run's pieces -- the first A_H0 in step 0 and the rest in step 1, or all of them in step 0 of a paired run
     constexpr int DMA_MAX = B_PER + A_PER, DMA_PER_G = (DMA_MAX + FN - 1) / FN;
-    static_assert(!RSTG || A_PER >= 6, "residual staging uses six of the run loader's slots in a step that loads no run");
-    // (RSTG) staged piece e of the tile being finished: e 0..2 = pixel row 1 (column pair 0, pair 1, last column), 3..5 = row 0;
-    // same descriptor and per-lane offsets as the epilogue's register loads, worked out here from an opaque copy of the lane id
-    // (once per tile: nothing may live across the main loop)
-    auto stage_res_piece = [&](int e) __attribute__((always_inline)) {
-        if constexpr (RSTG) {
-            const int row = e < 3 ? 1 : 0, which = e < 3 ? e : e - 3;
-            int l = lane;
-            asm volatile("" : "+v"(l));
-            const int lp = l & 15, lq = l >> 4;
-            const unsigned col = which < 2 ? (unsigned)(n0 + wn * TN + lq * 8 + which * 32)
-                                           : (unsigned)(n0 + wn * TN + (FN - 1) * 16 + lq * 4);
-            const unsigned voff = ((unsigned)(wm * TM + lp + row * 16) * (unsigned)p.ld_res + col) * 2u;
-            const long long rows_left = (long long)p.M - (long long)c_tile * BM;
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(p.res + (size_t)c_tile * BM * p.ld_res), 0, (int)min(rows_left * p.ld_res * 2, 0x7fffffffLL), 0x00020000);
-            const int dst = (row == 0 ? pa * A_BUF : STG_FREE_OFF) + wave * v5_stg_row_bytes + which * 1024;
-            MDHIP_DMA16(rr, smem + dst, voff, 0);
-        }
-    };
     for (int run = 0; run < total_runs; ++run) {
         const bool last_cg = c_cg == G - 1;
         const bool tile_end = c_r == 2 && last_cg;
@@ -738,7 +682,6 @@ conv_v5_kernel(const ConvArgs p) {
                     if (d < B_PER) dma_b_piece(cur, d);
                     else if (s == 0 && (d - B_PER < A_H0 || pair_run)) dma_run_piece(pa ^ 1, d - B_PER);
                     else if (s == 1 && A_H0 + d - B_PER < A_PER) dma_run_piece(pa ^ 1, A_H0 + d - B_PER);
-                    else if (RSTG && s == 2 && tile_end && d - B_PER < 6) stage_res_piece(d - B_PER);
                 }
                 MDHIP_FENCE();
             }
@@ -752,7 +695,7 @@ conv_v5_kernel(const ConvArgs p) {
         c_r = n_r;
         if (n_r == 0 && ++c_cg == G) {
             c_cg = 0;
-            epilogue(c_tile, pa ^ 1);            // (pa was toggled above: pa ^ 1 is the buffer of the run just consumed)
+            epilogue(c_tile);
             after_epilogue = true;
             c_tile += tile_step;
         }
@@ -837,10 +780,6 @@ hipError_t conv5_init() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 1, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 2, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
-        const int st_lds = al_lds + v5_stg_extra_lds((wm) * (wn));                               \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn), v5_can_stage(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, st_lds); \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 1, v5_is_lean(bm, bn, wm, wn), v5_can_stage(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, st_lds); \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 2, v5_is_lean(bm, bn, wm, wn), v5_can_stage(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, st_lds); \
     }                                                                                          \
     if (e == hipSuccess)                                                                       \
         e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0>,             \
@@ -893,20 +832,9 @@ hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     const int tail = !tail_short ? 0 : (a.wgt4p != nullptr ? 2 : 1);
     // the 8-wave tiles' aligned mode (conv_v5_kernel AL): a wave's 80 pixels inside one image row; same results
     const bool aligned = (a.W % 80) == 0 && a.dev_param != 77;
-    // residual staging (conv_v5_kernel RSTG): aligned 8-wave launches with a residual operand; MDHIP_RSTG=0 / dev_param 78 switch it
-    // off (A/B and the bit-identity test: same operands, same arithmetic, the residual only arrives by another road)
-    const char* rstg_env = getenv("MDHIP_RSTG");          // (read per launch: the bit-identity test toggles it inside one process)
-    const bool stage_res = a.res != nullptr && !(rstg_env && rstg_env[0] == '0') && a.dev_param != 78;
     switch (cfg) {
 #define X(id, bm, bn, wm, wn, prof)                                                               \
     case id:                                                                                    \
-        if (v5_can_stage(bm, bn, wm, wn) && aligned && stage_res) {                               \
-            const size_t st_lds = c.lds_bytes + v5_al_extra_lds + v5_stg_extra_lds((wm) * (wn));    \
-            if (tail == 0) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn), v5_can_stage(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), st_lds, s, p); \
-            else if (tail == 1) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 1, v5_is_lean(bm, bn, wm, wn), v5_can_stage(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), st_lds, s, p); \
-            else hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 2, v5_is_lean(bm, bn, wm, wn), v5_can_stage(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), st_lds, s, p); \
-            break;                                                                              \
-        }                                                                                       \
         if (v5_is_lean(bm, bn, wm, wn) && aligned) {                                            \
             const size_t al_lds = c.lds_bytes + v5_al_extra_lds;                                  \
             if (tail == 0) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), al_lds, s, p); \
