@@ -358,7 +358,11 @@ int main(int argc, char** argv) {
             }
             static const char* nm5[6] = {"half1 (reads Y + mfma X)", "waitcnt vmcnt/lgkmcnt", "barrier", "half2 (dma + reads X + mfma Y)",
                                          "first step after an epilogue: wait + barrier", "epilogue (amortised)"};
-            const char* const* nm = nm5;
+            static const char* nm_epi[6] = {"epilogue pixel row 0", "epilogue pixel row 1", "epilogue pixel row 2", "epilogue pixel row 3",
+                                            "epilogue pixel row 4", "everything else (main loop, waits, barriers)"};
+            const char* cname = cfg <= -301 && cfg > -401 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : "";
+            const int prof_bits = strrchr(cname, '/') ? atoi(strrchr(cname, '/') + 1) : 0;
+            const char* const* nm = (prof_bits & 128) ? nm_epi : nm5;
             double tot = 0;
             for (int k = 0; k < 6; ++k) tot += sum[k];
             printf("    %d waves, %.0f steps each; cycles per step: total %.0f\n", waves, steps / waves, tot / steps);
