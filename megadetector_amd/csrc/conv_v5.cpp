@@ -40,6 +40,11 @@
 
 #include "mdhip_internal.h"
 
+// residual pixel rows in flight ahead of the one being finished in the 8-wave tiles' epilogue (developer switch for A/B builds)
+#ifndef MDHIP_V5_RA
+#define MDHIP_V5_RA 2
+#endif
+
 namespace mdhip {
 namespace MDHIP_ST {
 
@@ -92,12 +97,7 @@ constexpr int v5_waves_per_simd(int bm, int bn, int nw) {
 // 9-bit mask per lane and fragment: one address register for fragments 1..3 (fragment i at the immediate offset i * 2048, a
 // row of zeros at each of those offsets for a wave whose tap falls above / below the image), two for the edge fragments;
 // 5-6 VALU instructions a step instead of ~36 (a select per fragment, the shift arithmetic, the k-half XOR per fragment).
-// ERES ("early residual", aligned 8-wave tiles launched with a residual operand) [r5]: the residual of the epilogue's FIRST pixel row is
-// requested (ordinary buffer loads into the epilogue's own register slot 0) at the start of the second half of the tile's LAST step, about
-// one half step before the epilogue begins, and the epilogue then opens with rows 1 and 2 -- three rows on their way instead of two, the
-// first of them a half step ahead.  Stamps (tools/convbench t16, profiles/r5_convbench_epilogue_rows.txt): the first pixel row of an
-// epilogue with residual takes 6 700 - 7 300 cycles against 2 000 without -- the round trip of its residual, fully exposed.
-template <int BM, int BN, int WM, int WN, int PROF = 0, int TAIL = -1, bool AL = false, bool ERES = false>
+template <int BM, int BN, int WM, int WN, int PROF = 0, int TAIL = -1, bool AL = false>
 __global__ void __launch_bounds__(WM * WN * 64, v5_waves_per_simd(BM, BN, WM * WN))
 conv_v5_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -111,7 +111,6 @@ conv_v5_kernel(const ConvArgs p) {
     constexpr int B_OFF = 2 * A_BUF;
     constexpr int ZERO_OFF = B_OFF + 2 * B_BYTES;
     static_assert(TM % 16 == 0 && TN % 16 == 0, "16x16 fragments");
-    static_assert(!ERES || (FM == 5 && FN == 5), "early residual: the 8-wave tiles (three residual register slots)");
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lds_char* const smem = (lds_char*)smem_generic;
@@ -375,9 +374,6 @@ conv_v5_kernel(const ConvArgs p) {
             t_prev = t;
         }
     };
-    // (ERES) the residual of the epilogue's pixel row 0, requested in the tile's last step: slot 0 of the epilogue's ring
-    [[maybe_unused]] uint4 eres_pair[2];
-    [[maybe_unused]] uint2 eres_last;
     // ---- epilogue (bias staged in LDS, pixel-row order, packed SiLU, 16-byte buffer stores) ----------
     const int q4 = lane >> 4;
     auto epilogue_t = [&](int tile_m, auto has_res_t, auto out_f32_t, auto act_t) __attribute__((always_inline)) {
@@ -442,7 +438,7 @@ conv_v5_kernel(const ConvArgs p) {
         // residual rows in flight ahead of the row being finished: 1 (two workgroups per CU: the partner workgroup's
         // MFMAs cover the round trip) or 2 (LEAN = one 8-wave workgroup per CU: every wave of the CU is in its epilogue
         // at the same time, and each pixel row would otherwise wait out most of an HBM round trip on its own)
-        constexpr int RA = LEAN ? 2 : 1, RS = RA + 1;     // (all five rows up front, round 4: 1 - 4 % slower)
+        constexpr int RA = LEAN ? MDHIP_V5_RA : 1, RS = RA + 1;     // (all five rows up front, round 4: 1 - 4 % slower; three, round 5: see MDHIP_V5_RA)
         uint4 rpair[RS][NPAIR > 0 ? NPAIR : 1];
         uint2 rlast[RS];
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -464,25 +460,13 @@ conv_v5_kernel(const ConvArgs p) {
             }
         };
         if constexpr ((PROF & 129) == 129) stamp(5);
-        constexpr bool EARLY = ERES && HAS_RES;
-        if constexpr (EARLY) {
-            // row 0 has been on its way since the tile's last step (eres_*); rows 1 and 2 follow now, row i + 2 when row i - 1 ... no:
-            // row i + 2 is requested when row i is taken up, into the slot row i - 1 has left (i >= 1)
-            static_assert(RS == 3 && NPAIR == 2, "early residual: three slots of two column pairs");
-            fetch_res_row(1, rpair[1], rlast[1]);
-            fetch_res_row(2, rpair[2], rlast[2]);
-            rpair[0][0] = eres_pair[0];
-            rpair[0][1] = eres_pair[1];
-            rlast[0] = eres_last;
-        } else if constexpr (HAS_RES) {
+        if constexpr (HAS_RES) {
 #pragma unroll
             for (int a = 0; a < RA && a < FM; ++a) fetch_res_row(a, rpair[a % RS], rlast[a % RS]);
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            if constexpr (EARLY) {
-                if (i >= 1 && i + RA < FM) fetch_res_row(i + RA, rpair[(i + RA) % RS], rlast[(i + RA) % RS]);
-            } else if constexpr (HAS_RES) {
+            if constexpr (HAS_RES) {
                 if (i + RA < FM) fetch_res_row(i + RA, rpair[(i + RA) % RS], rlast[(i + RA) % RS]);
             }
             const int m = m0 + i * 16;
@@ -562,7 +546,7 @@ conv_v5_kernel(const ConvArgs p) {
         if constexpr (LEAN) {
             // (s_setprio 2 on the first four waves for the epilogue -- so that one wave of a SIMD computes while the other waits
             // for the memory path -- was measured: no difference on any layer, profiles/r4_convbench_epilogue_prio.txt)
-            if (ERES || p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::true_type{});
+            if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::true_type{});
             else epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::true_type{});
         } else {
             if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{}, std::false_type{});
@@ -692,35 +676,6 @@ conv_v5_kernel(const ConvArgs p) {
             after_epilogue = false;
             MDHIP_FENCE();
 
-            if constexpr (ERES) {
-                if (s == 2) {
-                    if (tile_end) {
-                        // (descriptor and offsets as in the epilogue, from an opaque copy of the lane id: nothing lives across the loop)
-                        int l = lane;
-                        asm volatile("" : "+v"(l));
-                        const int lp = l & 15, lq = l >> 4;
-                        const unsigned row = (unsigned)(wm * TM + lp) * (unsigned)p.ld_res;
-                        const unsigned v_pair = (row + (unsigned)(n0 + wn * TN + lq * 8)) * 2u;
-                        const unsigned v_last = (row + (unsigned)(n0 + wn * TN + (FN - 1) * 16 + lq * 4)) * 2u;
-                        const long long rows_left = (long long)p.M - (long long)c_tile * BM;
-                        // (The ten destination registers are kept for these loads alone -- they are live around the whole loop, there is no
-                        // "defined on the other path" trick: when the allocator may reuse them, the compiler guards the reusing
-                        // instructions, the first MFMAs of the next run, with s_waitcnt vmcnt(2..3), which also waits for the weight
-                        // pieces just requested; written as inline asm the loads are invisible to it and it copies the registers
-                        // before the data has arrived.  Both seen in the ISA.)
-                        typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
-                        typedef __attribute__((ext_vector_type(2))) unsigned eu32x2;
-                        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                            (void*)(p.res + (size_t)c_tile * BM * p.ld_res), 0, (int)min(rows_left * p.ld_res * 2, 0x7fffffffLL), 0x00020000);
-                        const eu32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)v_pair, 0, 0);
-                        const eu32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(v_pair + 64u), 0, 0);
-                        const eu32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)v_last, 0, 0);
-                        eres_pair[0] = make_uint4(t0[0], t0[1], t0[2], t0[3]);
-                        eres_pair[1] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
-                        eres_last = make_uint2(t2[0], t2[1]);
-                    }
-                }
-            }
             // ---- second half: the k 0..31 fragments of the next step, MFMAs on k 32..63, and the DMA
             //      pieces (weight slab of step+2; in steps 0 and 1 the next run) behind the MFMA chunks ----
 #pragma unroll
@@ -845,9 +800,6 @@ hipError_t conv5_init() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 1, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 2, v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn), v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 1, v5_is_lean(bm, bn, wm, wn), v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 2, v5_is_lean(bm, bn, wm, wn), v5_is_lean(bm, bn, wm, wn)>, hipFuncAttributeMaxDynamicSharedMemorySize, al_lds); \
     }                                                                                          \
     if (e == hipSuccess)                                                                       \
         e = hipFuncSetAttribute((const void*)conv_v5_kernel<bm, bn, wm, wn, prof, 0>,             \
@@ -900,22 +852,9 @@ hipError_t conv5_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     const int tail = !tail_short ? 0 : (a.wgt4p != nullptr ? 2 : 1);
     // the 8-wave tiles' aligned mode (conv_v5_kernel AL): a wave's 80 pixels inside one image row; same results
     const bool aligned = (a.W % 80) == 0 && a.dev_param != 77;
-    // early residual (conv_v5_kernel ERES): aligned 8-wave launches with a residual operand; MDHIP_ERES=0 switches it off (A/B and the
-    // bit-identity test: same operands, same arithmetic -- the first residual row is only requested earlier)
-    const char* eres_env = getenv("MDHIP_ERES");
-    // (not for the paired-tail instantiation: ten more registers spill there -- 254 + 20 bytes of scratch, reloads behind vmcnt(0))
-    const bool early_res = a.res != nullptr && !(eres_env && eres_env[0] == '0') && a.dev_param != 78 &&
-                           !(tail_short && a.wgt4p != nullptr && !(eres_env && eres_env[0] == '2'));
     switch (cfg) {
 #define X(id, bm, bn, wm, wn, prof)                                                               \
     case id:                                                                                    \
-        if (v5_is_lean(bm, bn, wm, wn) && aligned && early_res) {                               \
-            const size_t al_lds = c.lds_bytes + v5_al_extra_lds;                                  \
-            if (tail == 0) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn), v5_is_lean(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), al_lds, s, p); \
-            else if (tail == 1) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 1, v5_is_lean(bm, bn, wm, wn), v5_is_lean(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), al_lds, s, p); \
-            else hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 2, v5_is_lean(bm, bn, wm, wn), v5_is_lean(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), al_lds, s, p); \
-            break;                                                                              \
-        }                                                                                       \
         if (v5_is_lean(bm, bn, wm, wn) && aligned) {                                            \
             const size_t al_lds = c.lds_bytes + v5_al_extra_lds;                                  \
             if (tail == 0) hipLaunchKernelGGL((conv_v5_kernel<bm, bn, wm, wn, prof, 0, v5_is_lean(bm, bn, wm, wn)>), grid, dim3((wm) * (wn) * 64), al_lds, s, p); \

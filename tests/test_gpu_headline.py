@@ -633,46 +633,3 @@ def test_aligned_mode_of_the_8_wave_tiles_is_bit_identical_to_the_general_tiles(
     finally:
         ctx.close()
 
-
-@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
-def test_early_residual_of_the_8_wave_tiles_is_bit_identical(dtype, monkeypatch):
-    """[r5] conv_v5.cpp ERES: in the aligned 8-wave launches with a residual operand (the backbone bottleneck 3x3s of the
-    320-channel C3 block, layer 6; with MDHIP_ERES=2 also the paired-tail instantiation of the 160-channel block, layer 4) the
-    residual of the epilogue's first pixel row is requested in the second half of the tile's LAST step instead of at the
-    epilogue's start.  Same operands, same arithmetic -- the row only sets out earlier: the SAME BITS as with MDHIP_ERES=0,
-    arena poisoned, for a batch, for single images, on maps of 2 .. 40 tiles per image."""
-    from megadetector_amd import weights_io, yolo_yaml
-    from megadetector_amd.hip_backend import HipContext
-    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5X6_MD, seed=0)
-    monkeypatch.setenv('MDHIP_ARENA_POISON', '1')
-    for (n, hh, ww) in ((3, 128, 1280), (2, 640, 1280), (1, 1280, 1280)):
-        imgs = PU.structured_images(n, hh, ww, seed=31 + hh)
-        ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
-        try:
-            names = {ctx.conv_cfg_name(c): c for c in range(ctx.num_conv_cfgs())}
-            lean = names['v5:run320x160/4x2/0']
-            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
-            ctx.forward(n, hh, ww)
-            res_ops = [o for o in ctx.op_infos() if o['kind'] == 0 and o['ntaps'] == 9 and o['stride'] == 1 and o['has_res']
-                       and o['layer'] in (4, 6) and ctx.op_supports_cfg(o['op'], lean)]
-            assert len(res_ops) == 20, [o['name'] for o in res_ops]            # 8 + 12 backbone bottlenecks
-            for o in res_ops:
-                ctx.set_op_cfg(o['op'], lean)
-            out = {}
-            for flag in ('0', '1', '2'):
-                monkeypatch.setenv('MDHIP_ERES', flag)
-                ctx.forward(n, hh, ww)
-                ran = {ctx.conv_cfg_name(o['cfg']) for o in ctx.op_infos() if o['op'] in {r['op'] for r in res_ops}}
-                assert ran == {'v5:run320x160/4x2/0'}, ran
-                out[flag] = (ctx.read_predictions(n).copy(), ctx.read_layer(4, n).copy(), ctx.read_layer(6, n).copy())
-            assert np.isfinite(out['1'][0]).all()
-            for flag in ('1', '2'):
-                for a, b in zip(out['0'], out[flag]):
-                    np.testing.assert_array_equal(a, b)
-            monkeypatch.setenv('MDHIP_ERES', '1')
-            if n > 1:                                                   # an image alone: the same bits
-                ctx.preprocess([imgs[n - 1]], _identity_geoms([imgs[n - 1]]), hh, ww)
-                ctx.forward(1, hh, ww)
-                np.testing.assert_array_equal(ctx.read_predictions(1)[0], out['1'][0][n - 1])
-        finally:
-            ctx.close()
