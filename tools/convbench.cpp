@@ -367,6 +367,19 @@ int main(int argc, char** argv) {
             for (int k = 0; k < 6; ++k) tot += sum[k];
             printf("    %d waves, %.0f steps each; cycles per step: total %.0f\n", waves, steps / waves, tot / steps);
             for (int k = 0; k < 6; ++k) printf("      %-34s %8.1f  (%4.1f%%)\n", nm[k], sum[k] / steps, 100 * sum[k] / tot);
+            if (getenv("CONVBENCH_PER_WAVE")) {
+                // the same per wave index inside its workgroup (8-wave tiles: who waits at the barrier, who arrives last)
+                const int nwv = 8;
+                for (int wv = 0; wv < nwv; ++wv) {
+                    double s6[6] = {0, 0, 0, 0, 0, 0}, st = 0;
+                    for (size_t w = wv; w < dbg_words / 8; w += nwv) {
+                        if (!h[w * 8 + 6]) continue;
+                        st += (double)h[w * 8 + 6];
+                        for (int k = 0; k < 6; ++k) s6[k] += (double)h[w * 8 + k];
+                    }
+                    if (st > 0) printf("      wave %d: %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f\n", wv, s6[0] / st, s6[1] / st, s6[2] / st, s6[3] / st, s6[4] / st, s6[5] / st);
+                }
+            }
             CK(hipMemset(d_dbg, 0, dbg_words * 8));
         }
         fflush(stdout);
