@@ -40,11 +40,6 @@
 
 #include "mdhip_internal.h"
 
-// residual pixel rows in flight ahead of the one being finished in the 8-wave tiles' epilogue (developer switch for A/B builds)
-#ifndef MDHIP_V5_RA
-#define MDHIP_V5_RA 2
-#endif
-
 namespace mdhip {
 namespace MDHIP_ST {
 
@@ -438,7 +433,7 @@ conv_v5_kernel(const ConvArgs p) {
         // residual rows in flight ahead of the row being finished: 1 (two workgroups per CU: the partner workgroup's
         // MFMAs cover the round trip) or 2 (LEAN = one 8-wave workgroup per CU: every wave of the CU is in its epilogue
         // at the same time, and each pixel row would otherwise wait out most of an HBM round trip on its own)
-        constexpr int RA = LEAN ? MDHIP_V5_RA : 1, RS = RA + 1;     // (all five rows up front, round 4: 1 - 4 % slower; three, round 5: see MDHIP_V5_RA)
+        constexpr int RA = LEAN ? 2 : 1, RS = RA + 1;     // (all five rows up front, round 4: 1 - 4 % slower; three, round 5: + 0 .. 1 %)
         uint4 rpair[RS][NPAIR > 0 ? NPAIR : 1];
         uint2 rlast[RS];
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
