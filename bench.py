@@ -39,7 +39,9 @@ WEIGHT_GB = 0.28
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None,
+                    help='ranks = GPUs of this node.  Default: WORLD_SIZE when a launcher set it, else 1; given explicitly it '
+                         'must agree with the launcher')
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32)
@@ -93,18 +95,51 @@ def parse_args():
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: become the launcher the driver would be --
     one rank per GPU through torch.distributed.run on 127.0.0.1 (the reference's recipe is one command per GPU,
-    notebooks/manage_local_batch.py:617-621) -- and hand its exit code on.  Rank 0 of that run prints the one JSON line."""
-    import socket
+    notebooks/manage_local_batch.py:617-621) -- and hand its exit code on.  Rank 0 of that run prints the one JSON line.
+    The rendezvous port is the launcher's own choice (`--standalone`: its c10d store binds port 0), not a port probed here
+    and released again -- another process could take such a port before the launcher binds it."""
     import subprocess
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     print('bench.py: --gpus {} without WORLD_SIZE: launching {}'.format(args.gpus, ' '.join(cmd)), file=sys.stderr)
     return subprocess.call(cmd, env=env)
+
+
+def init_control_plane(torch, rank, world, local_rank, force_gloo, timeout_s=300, nccl_timeout_s=120):
+    """The process group of an N > 1 run.  The path has no data-path collective: the group only carries
+    the barriers around the timed region and the MAX over ranks.  A gloo group on the host is created FIRST and always --
+    it cannot fail for a reason that has to do with the GPUs -- then RCCL (backend 'nccl', one rank per GPU) is tried as
+    a second group: created, exercised with one all-reduce, and adopted only if EVERY rank got through (agreed over the
+    gloo group).  Returns (dist, group, on_host, name, why): `group` carries barriers / reductions (None = the default gloo
+    group), `on_host` says where its tensors live, `name` ('rccl' | 'gloo') goes into the JSON line, with `why` when RCCL
+    was not used."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+    if force_gloo:
+        return dist, None, True, 'gloo', 'asked for (MDHIP_BENCH_BACKEND=gloo or the one-GPU test hook)'
+    ok, why, group = 1, '', None
+    try:
+        group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=nccl_timeout_s),
+                               device_id=torch.device('cuda', local_rank))
+        t = torch.ones(1, device='cuda')
+        dist.all_reduce(t, group=group)
+        torch.cuda.synchronize()
+        if int(t.item()) != world:
+            raise RuntimeError('RCCL all-reduce returned {} for a world of {}'.format(int(t.item()), world))
+    except Exception as e:                                   # RCCL missing / refusing this box: the host plane carries on
+        ok, why = 0, '{}: {}'.format(type(e).__name__, str(e).splitlines()[0][:200] if str(e) else '')
+    flag = torch.tensor([ok], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)               # over gloo: every rank or none
+    if int(flag.item()) == 1:
+        return dist, group, False, 'rccl', ''
+    if ok:
+        why = 'another rank could not initialise RCCL'
+    print('rank {}: RCCL control plane not available ({}): barriers over gloo'.format(rank, why), file=sys.stderr)
+    return dist, None, True, 'gloo', why
 
 
 def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
@@ -441,12 +476,15 @@ def pmc_row_for_cfg(cfg_name):
 
 def main():
     args = parse_args()
+    gpus_given = args.gpus is not None
+    if not gpus_given:                                        # `torchrun --nproc-per-node N bench.py` without --gpus: N ranks
+        args.gpus = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
+    if gpus_given and world != args.gpus:
         raise SystemExit('bench.py: --gpus {} but WORLD_SIZE={}: launch with --nproc-per-node {} (or without a launcher: '
                          '`python bench.py --gpus N` starts the ranks itself)'.format(args.gpus, world, args.gpus))
     if args.rendezvous_check:
@@ -481,21 +519,12 @@ def main():
     if world > 1 or args.pin_cpus:                             # stdout carries the one JSON line and nothing else
         print('rank {}: {} CPUs{}'.format(rank, len(pinned_cpus), ' ({}..{})'.format(pinned_cpus[0], pinned_cpus[-1])
                                           if pinned_cpus else ''), file=sys.stderr)
-    dist = None
+    dist, group, control_plane, control_why = None, None, None, ''
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        import datetime
-        # the path has no data-path collective: the process group only carries the barriers around the timed
-        # region and the MAX over ranks.  RCCL by default (one rank per GPU); MDHIP_BENCH_BACKEND=gloo keeps that control
-        # plane on the host if RCCL cannot start on a box (and is what the one-GPU test hook uses)
-        gloo = one_gpu or os.environ.get('MDHIP_BENCH_BACKEND', 'nccl') == 'gloo'
-        if gloo:
-            dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-        else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300),
-                                    device_id=torch.device('cuda', local_rank))
-        one_gpu = gloo                                          # (from here on: "control tensors live on the host")
+        # RCCL when every rank can start it, gloo otherwise (init_control_plane); MDHIP_BENCH_BACKEND=gloo skips the attempt
+        force_gloo = one_gpu or os.environ.get('MDHIP_BENCH_BACKEND', 'nccl') == 'gloo'
+        dist, group, one_gpu, control_plane, control_why = init_control_plane(torch, rank, world, local_rank, force_gloo)
+        # (from here on one_gpu means "control tensors live on the host")
 
     from megadetector_amd import weights_io, yolo_yaml
     from megadetector_amd.postprocess import format_detections
@@ -515,7 +544,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=group)
         torch.cuda.synchronize()
 
     wl.prepare()                # fp8: static activation scales from the first synthetic batch (mdhip_calibrate), before anything is timed
@@ -544,11 +573,11 @@ def main():
     ctx.time_forwards(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if one_gpu else 'cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
         # per-rank rates (outside the timed region): exposes stragglers / NUMA effects on the first multi-GPU run
         allt = [torch.zeros(1, dtype=torch.float64, device='cpu' if one_gpu else 'cuda') for _ in range(world)]
-        dist.all_gather(allt, torch.tensor([my_elapsed], dtype=torch.float64, device='cpu' if one_gpu else 'cuda'))
+        dist.all_gather(allt, torch.tensor([my_elapsed], dtype=torch.float64, device='cpu' if one_gpu else 'cuda'), group=group)
         per_rank = [round(B * args.steps / float(x.item()), 2) for x in allt]
     else:
         per_rank = [round(B * args.steps / my_elapsed, 2)]
@@ -703,9 +732,26 @@ def main():
             except Exception as e:                   # a failing leg must not cost the headline line
                 extra[key] = {'error': '{}: {}'.format(type(e).__name__, e)}
 
+    # N > 1: the ranks part here -- the process group goes (nothing below is collective), every rank but 0 is done; rank 0
+    # still owes the CPU baseline ("timed on the same box's host cores in the same run", BASELINE.json north_star), which
+    # it runs AFTER the group is gone so that no rank waits in a barrier for 30 s of host work
+    if dist is not None:
+        dist.barrier(group=group)
+        dist.destroy_process_group()
+        dist = None
+    wl.close()
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        if world > 1 and hasattr(os, 'sched_setaffinity'):
+            # the rank was pinned to its GPU's share of the host; the baseline is the HOST's best, as in the N = 1 line
+            try:
+                os.sched_setaffinity(0, range(os.cpu_count() or 1))
+                torch.set_num_threads(len(os.sched_getaffinity(0)))
+            except OSError:
+                pass
         cpu = cpu_baseline(weights, S, args.threshold, args.cpu_seconds, single_thread=not args.no_cpu_single_thread)
+        if world > 1:
+            cpu['note'] = 'rank 0, after the timed region and after the process group was destroyed (the other ranks have exited)'
 
     if rank == 0:
         total_images = world * B * args.steps
@@ -738,12 +784,11 @@ def main():
             'extra_configs': extra,
             'per_rank_images_per_s': per_rank,
             'pinned_cpus': len(pinned_cpus) if (world > 1 or args.pin_cpus) else None,
+            'control_plane': control_plane,
         }
+        if control_why:
+            line['control_plane_note'] = control_why
         print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    wl.close()
 
 
 if __name__ == '__main__':

@@ -34,6 +34,66 @@ def test_bench_gpus_n_launches_its_own_ranks():
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and sorted(line['ranks']) == [0, 1]
     assert 'torch.distributed.run' in r.stderr and '--nproc-per-node 2' in r.stderr
+    # the launcher picks its own rendezvous port (no bind-then-release probe that another process could win)
+    assert '--standalone' in r.stderr and '--master-port' not in r.stderr
+
+
+def test_bench_without_gpus_takes_the_launchers_world_size():
+    # `torchrun --nproc-per-node 2 bench.py` (no --gpus): two ranks, one line; an explicit --gpus must still agree
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+                        '--nproc-per-node', '2', os.path.join(REPO, 'bench.py'), '--rendezvous-check'],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+
+
+_CONTROL_PLANE_RANK = r'''
+import os, sys, json
+sys.path.insert(0, {repo!r})
+import torch, bench
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+if os.environ.get('FAIL_ON_RANK') == str(rank):
+    # one rank alone cannot start the device plane: every rank has to end up on the host plane
+    import torch.distributed as d
+    real = d.new_group
+    def broken(*a, **k):
+        if k.get('backend') == 'nccl':
+            raise RuntimeError('injected: no RCCL on this rank')
+        return real(*a, **k)
+    d.new_group = broken
+dist, group, on_host, name, why = bench.init_control_plane(torch, rank, world, 0, os.environ.get('FORCE_GLOO') == '1',
+                                                           timeout_s=120, nccl_timeout_s=20)
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+dist.barrier(group=group)
+allr = [None] * world
+dist.all_gather_object(allr, [name, on_host, bool(why)])
+if rank == 0:
+    print(json.dumps({{'planes': allr, 'max': float(t.item())}}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('mode', ['no_device_plane', 'one_rank_fails', 'forced'])
+def test_control_plane_falls_back_to_gloo_on_every_rank(tmp_path, mode):
+    """bench.py's N > 1 process group (init_control_plane): RCCL is tried as a second group and adopted only if EVERY rank
+    got through; here no rank can (no GPU) / one rank is made to fail / the attempt is skipped -- the barriers and the MAX
+    over ranks must work over gloo on all ranks either way, and every rank must report the same plane."""
+    script = tmp_path / 'rank.py'
+    script.write_text(_CONTROL_PLANE_RANK.format(repo=REPO))
+    env = _env()
+    if mode == 'one_rank_fails':
+        env['FAIL_ON_RANK'] = '1'
+    if mode == 'forced':
+        env['FORCE_GLOO'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+                        '--nproc-per-node', '2', str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['max'] == 2.0
+    assert [p[0] for p in out['planes']] == ['gloo', 'gloo'] and all(p[1] for p in out['planes'])
+    assert all(p[2] for p in out['planes'])                 # each rank says why RCCL is not carrying the barriers
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
