@@ -109,6 +109,11 @@ const char* mdhip_last_error(mdhip_ctx* ctx);
  * :1283-1310).  images[i]: HWC uint8 RGB, src_h x src_w, host or device memory
  * (host images are copied to a device staging area first).  Output: the context's network input,
  * n x out_h x out_w.  out_h/out_w must be multiples of the model's largest stride.
+ * Device images: the kernels read whole aligned dwords, so for an image pointer (or row pitch src_w * 3) that is not a
+ * multiple of 4 up to 3 bytes in front of the first and behind the last pixel are READ (never used, never written): they
+ * lie in the same aligned dword as an image byte, i.e. inside any hipMalloc'ed block that holds the image, but a
+ * memory checker that tracks exact extents will report them.  (MDHIP_LETTERBOX_GENERAL in the environment at
+ * mdhip_create selects the byte-wise kernel for every batch.)
  * Streams: the call may be enqueued on another stream than the forwards -- it first makes its stream wait
  * (hipStreamWaitEvent, inside the library) for the last mdhip_forward / mdhip_forward_tta enqueued before it to have read
  * the network input (the stem), so the letterbox of batch i + 1 can run next to the rest of forward i; the forward of
@@ -254,6 +259,11 @@ int mdhip_set_fuse(mdhip_ctx* ctx, int on);
  * arguments: bit-identical results.  mdhip_forward_tta and the timed / per-op entry points are not replayed.
  * Replaces nothing in the reference (pytorch_detector.py:1313 runs eager PyTorch); this is launch plumbing. */
 int mdhip_set_graph(mdhip_ctx* ctx, int mode, int max_n);
+/* Named integer switches of a context (returns MDHIP_EINVAL for an unknown name; every change drops the captured graphs):
+ *   "letterbox_general" 0 | 1   1 = mdhip_preprocess never takes the streaming-copy kernel (A/B measurements, tests;
+ *                               the environment variable MDHIP_LETTERBOX_GENERAL at mdhip_create sets the same switch)
+ * Replaces nothing in the reference; the switches exist for measurements and tests. */
+int mdhip_set_option(mdhip_ctx* ctx, const char* name, int value);
 /* time one op in isolation: `iters` back-to-back launches bracketed by events */
 int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float* ms_avg,
                   void* hip_stream);

@@ -91,6 +91,7 @@ SYMBOLS = {
     'mdhip_set_tuned': (C.c_int, [_P, C.POINTER(mdhip_tuned), C.c_int]),
     'mdhip_set_fuse': (C.c_int, [_P, C.c_int]),
     'mdhip_set_graph': (C.c_int, [_P, C.c_int, C.c_int]),
+    'mdhip_set_option': (C.c_int, [_P, C.c_char_p, C.c_int]),
     'mdhip_time_op': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     'mdhip_version': (C.c_char_p, []),
 }

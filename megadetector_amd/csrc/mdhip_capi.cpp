@@ -141,6 +141,7 @@ struct mdhip_ctx {
     std::vector<std::vector<int>> fuse_groups;
     bool fuse_enabled = true, fuse_suspended = false;
     bool pair_enabled = true;         // paired taps of a half-full last channel group (conv_v5.cpp); MDHIP_PAIR=0 at create: off
+    bool letterbox_general = false;   // MDHIP_LETTERBOX_GENERAL at create: never take the streaming-copy letterbox (A/B, tests)
     std::vector<hipEvent_t> events;
     std::vector<mdhip_tuned> tuned;   // measured tile choices (tools/autotune.py)
     // optional event pair around every mdhip_forward (bench.py's live roofline measurement)
@@ -1097,6 +1098,7 @@ int mdhip_create(const mdhip_model* model, int device, int dtype, int max_batch,
     mdhip_ctx* ctx = new mdhip_ctx();
     if (const char* ef = getenv("MDHIP_FUSE")) ctx->fuse_enabled = atoi(ef) != 0;      // A/B measurements
     if (const char* ep = getenv("MDHIP_PAIR")) ctx->pair_enabled = atoi(ep) != 0;      // A/B measurements, bit-identity test
+    ctx->letterbox_general = getenv("MDHIP_LETTERBOX_GENERAL") != nullptr;             // (read once, not per mdhip_preprocess)
     ctx->device = device;
     ctx->dtype = dtype;
     ctx->max_batch = max_batch;
@@ -1333,7 +1335,7 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
     }
     // the forward that still reads the input tensor (its stem) comes first, whatever stream it runs on
     if (ctx->input_free_valid) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->input_free, 0));
-    bool no_resampling = getenv("MDHIP_LETTERBOX_GENERAL") == nullptr;
+    bool no_resampling = !ctx->letterbox_general;
     for (int i = 0; i < n; ++i) no_resampling = no_resampling && g[i].resized_h == g[i].src_h && g[i].resized_w == g[i].src_w;
     if (!letterbox_geometry_travels_inline(n, out_w, no_resampling)) {
         // geometry goes through a 4-deep pinned ring so that the call never blocks on the stream
@@ -1834,6 +1836,14 @@ int mdhip_set_tuned(mdhip_ctx* ctx, const mdhip_tuned* entries, int n) {
 int mdhip_set_fuse(mdhip_ctx* ctx, int on) {
     if (!ctx) return MDHIP_EINVAL;
     ctx->fuse_enabled = on != 0;
+    drop_graphs(ctx);
+    return MDHIP_OK;
+}
+
+int mdhip_set_option(mdhip_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return MDHIP_EINVAL;
+    if (!strcmp(name, "letterbox_general")) ctx->letterbox_general = value != 0;
+    else return fail(ctx, MDHIP_EINVAL, "unknown option '%s'", name);
     drop_graphs(ctx);
     return MDHIP_OK;
 }

@@ -286,6 +286,10 @@ class HipContext:
         """fused bottleneck launches on (default) / off (the 1x1 and the 3x3 as two launches: same bits)"""
         self._check(self.lib.mdhip_set_fuse(self.h, 1 if on else 0), 'mdhip_set_fuse')
 
+    def set_option(self, name, value):
+        """named integer switch of the context (include/mdhip.h: mdhip_set_option)"""
+        self._check(self.lib.mdhip_set_option(self.h, name.encode(), int(value)), 'mdhip_set_option({})'.format(name))
+
     def set_graph(self, mode, max_n=0):
         """graph replay of forward(): 0 / False = off, 1 / True = every forward, 2 / 'auto' = forwards of at most max_n
         images (default 8); same kernels and arguments, bit-identical results (include/mdhip.h: mdhip_set_graph)"""

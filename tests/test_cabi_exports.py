@@ -149,6 +149,10 @@ def test_shipped_tile_tables_name_configurations_of_this_build(table):
     assert len(entries) > 100
     unknown = sorted({e['name'] for e in entries if e.get('name') and e['name'] not in names})
     assert not unknown, unknown
+    # the numeric id next to a name is the id of THAT name in this build (a C-ABI caller may hand the ids to
+    # mdhip_set_tuned as they are; tools/normalize_tables.py rewrites them after the dispatch table changed)
+    stale = sorted({(e['name'], e['cfg'], names[e['name']]) for e in entries if e.get('name') and e.get('cfg') != names[e['name']]})
+    assert not stale, ('run tools/normalize_tables.py', stale[:5])
     fam = {}
     for e in entries:
         if not e.get('name'):

@@ -94,7 +94,7 @@ def test_preprocess_streaming_copy_kernel_bit_exact(n6, shape, monkeypatch):
     (aligned dword loads + a u8 -> storage-type table in LDS + 16-byte stores): bit-exact against the oracle's letterbox
     (reference pytorch_detector.py:1104-1109, :1283-1306) for row lengths that are not multiples of four bytes (every row
     starts at another alignment), padding on the left / right / top / bottom, device pointers at odd addresses, and the
-    same bits as the general kernel (MDHIP_LETTERBOX_GENERAL=1)."""
+    same bits as the general kernel (mdhip_set_option "letterbox_general")."""
     from megadetector_amd.postprocess import letterbox_geometry
     W, ctx = n6
     g = letterbox_geometry(shape, new_shape=256, stride=64)
@@ -117,9 +117,12 @@ def test_preprocess_streaming_copy_kernel_bit_exact(n6, shape, monkeypatch):
     torch.cuda.synchronize()
     ctx.preprocess(ptrs, geoms, h, w)
     np.testing.assert_array_equal(ctx.read_input(3, h, w), want)
-    monkeypatch.setenv('MDHIP_LETTERBOX_GENERAL', '1')
-    ctx.preprocess(ptrs, geoms, h, w)
-    np.testing.assert_array_equal(ctx.read_input(3, h, w), want)
+    ctx.set_option('letterbox_general', 1)
+    try:
+        ctx.preprocess(ptrs, geoms, h, w)
+        np.testing.assert_array_equal(ctx.read_input(3, h, w), want)
+    finally:
+        ctx.set_option('letterbox_general', 0)
 
 
 # ---------------------------------------------------------------------------------------
