@@ -476,6 +476,7 @@ int conv_num_v1_cfgs() { return kNumV1; }
 namespace {
 bool conv2_supports_l(int cfg, const ConvArgs& a) {
     if (conv2_cfg_is_ring(cfg) && !(conv2_is_pointwise(a) && a.k_pad >= 3 * 64)) return false;
+    if (conv2_cfg_is_pf(cfg) && !conv2_pf_supports(a)) return false;
     return conv2_supports(a) && (a.in_up == nullptr || cfg == 0);                    // in_up: 160x160 only
 }
 // one row per kernel family after the first: local configuration ids [0, num()), developer variants

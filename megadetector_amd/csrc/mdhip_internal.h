@@ -252,6 +252,8 @@ struct ConvCfg {
     const ConvCfg& conv2_cfg(int i); \
     bool conv2_supports(const ConvArgs& a); \
     bool conv2_cfg_is_ring(int cfg); \
+    bool conv2_cfg_is_pf(int cfg); \
+    bool conv2_pf_supports(const ConvArgs& a); \
     bool conv2_is_pointwise(const ConvArgs& a); \
     hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s); \
     hipError_t conv2_init(); \

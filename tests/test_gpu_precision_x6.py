@@ -229,13 +229,19 @@ def test_sparse_fixture_detection_lists_after_both_sides_own_nms(x6_sparse_check
           'threshold on both sides: conf {:.4f} coord {:.4f}'.format(
               dtype, above[0], above[1], SPARSE_THR, [len(r['detections']) for r in got], [len(q['detections']) for q in want],
               d_conf, worst[0], worst[1], bar_conf, bar_coord, plain[0], plain[1]))
+    inside = worst[0] <= bar_conf + 1e-9 and worst[1] <= bar_coord + 1e-9 and d_conf <= 0.005
     if dtype == 'fp16':
         # ENFORCED at the reference's bars: categories exact (unmatched = its own confidence >= 0.2 as error), |d conf| <= 0.005,
         # |d coord| <= 0.001 + two integer-pixel flips of the 2560-pixel originals
         assert worst[0] <= bar_conf + 1e-9 and worst[1] <= bar_coord + 1e-9, (dtype, worst)
         assert d_conf <= 0.005, d_conf
     else:
-        # bf16 / fp8 on THIS conditioning (input-dependent logit signal amplified until it is only 6 .. 12 bf16 roundings
-        # wide): reported, not at the reference's bar -- measured on the CPU emulation: bf16 |d conf| 0.028 over all anchors and
-        # detections that change sides of the threshold; the bound below only catches a broken kernel
+        # bf16 / fp8 are THROUGHPUT storage types: on this conditioning they do not meet the reference's list-level bars
+        # (profiles/r6_bf16_storage_study.txt: no head-sized set of fp16 tensors brings bf16 inside on every conditioning,
+        # only fp16 everywhere does).  The bound catches a broken kernel; the gap to the real bars is reported as an
+        # expected failure so that it shows in the pytest summary instead of hiding behind a loose assert.
         assert d_conf <= (0.06 if dtype == 'bf16' else 0.25), (dtype, d_conf)
+        if not inside:
+            pytest.xfail('{} storage is outside the reference\'s bars on the sparse fixture: compare_detection_lists conf {:.4f} / '
+                         'coord {:.4f} against {} / {:.4f}, |d conf| over all anchors {:.4f} against 0.005 (fp16 storage, the '
+                         'detector\'s default, is enforced at these bars)'.format(dtype, worst[0], worst[1], bar_conf, bar_coord, d_conf))

@@ -48,6 +48,15 @@ static const Shape kShapes[] = {
     {"l2_1x1", 32, 320, 320, 80, 80, 1, 1, false},
     {"l26_cv3", 32, 80, 80, 640, 640, 1, 1, false},
     {"l2_cv3", 32, 320, 320, 160, 160, 1, 1, false},
+    {"l19_cv12", 32, 80, 80, 1280, 640, 1, 1, false},   // M 204800 N 640 K 1280 (C3.cv1|cv2 behind a concat)
+    {"l23_cv12", 32, 160, 160, 640, 320, 1, 1, false},  // M 819200 N 320 K 640
+    {"l20_1x1", 32, 80, 80, 640, 320, 1, 1, false},     // M 204800 N 320 K 640
+    {"l8_cv3", 32, 40, 40, 960, 960, 1, 1, false},      // M 51200 N 960 K 960
+    {"l15_cv12", 32, 40, 40, 1920, 960, 1, 1, false},   // M 51200 N 960 K 1920
+    {"l29_cv12", 32, 40, 40, 1280, 960, 1, 1, false},   // M 51200 N 960 K 1280
+    {"l4_cv3", 32, 160, 160, 320, 320, 1, 1, false},    // M 819200 N 320 K 320
+    {"l10_cv3", 32, 20, 20, 1280, 1280, 1, 1, false},   // M 12800 N 1280 K 1280
+    {"l8_1x1", 32, 40, 40, 480, 480, 1, 1, false},      // M 51200 N 480 K 480
     {"l1_s2", 32, 640, 640, 80, 160, 3, 2, false},      // M 3276800 N 160 K 720
     {"l3_s2", 32, 320, 320, 160, 320, 3, 2, false},
     {"l5_s2", 32, 160, 160, 320, 640, 3, 2, false},
