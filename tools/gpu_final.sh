@@ -5,7 +5,7 @@
 # only).  usage on the GPU box:  ROUND=4 bash tools/gpu_final.sh      (tables are NOT re-tuned here: tools/retune_all.sh)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-R=${ROUND:-5}
+R=${ROUND:-6}
 O=gpurun_out/final$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -37,8 +37,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --pmc $C -d "$RP/$O/traffic_$C" -o t --output-format csv -- \
      python "$RP/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --lean > "$RP/$O/traffic_$C.log" 2>&1)
 done
-python tools/hbm_traffic.py $O/traffic_FETCH_SIZE $O/traffic_WRITE_SIZE YOLOV5X6_MD:32:1280 $O/hbm_traffic.json > $O/hbm_traffic.log 2>&1
-find $O/traffic_FETCH_SIZE $O/traffic_WRITE_SIZE -type f -size +1M -delete 2>/dev/null
+python tools/hbm_traffic.py $O/traffic_FETCH_SIZE $O/traffic_WRITE_SIZE YOLOV5X6_MD:32:1280 $O/hbm_traffic.json $O/ops_b32.json $O/hbm_traffic_by_kernel.txt > $O/hbm_traffic.log 2>&1
+# (the per-dispatch CSVs are kept when small enough: they are what the per-op alignment reads)
+find $O/traffic_FETCH_SIZE $O/traffic_WRITE_SIZE -type f -size +8M -delete 2>/dev/null
 stamp "trace + traffic"
 left && { bash tools/pmc_bench.sh final$R > $O/pmc_bench.log 2>&1; cp gpurun_out/pmc_final$R.txt gpurun_out/pmc_final$R.json $O/ 2>/dev/null; }
 stamp "pmc"
