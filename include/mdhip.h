@@ -262,6 +262,10 @@ int mdhip_set_graph(mdhip_ctx* ctx, int mode, int max_n);
 /* Named integer switches of a context (returns MDHIP_EINVAL for an unknown name; every change drops the captured graphs):
  *   "letterbox_general" 0 | 1   1 = mdhip_preprocess never takes the streaming-copy kernel (A/B measurements, tests;
  *                               the environment variable MDHIP_LETTERBOX_GENERAL at mdhip_create sets the same switch)
+ *   "fuse_decode"       1 | 0   1 (default) = the Detect decode (yolov5 Detect.forward, pytorch_detector.py:1313) runs in the
+ *                               epilogue of each level's 1x1 conv -- no fp32 logits tensor, four launches fewer -- for heads
+ *                               with 8 outputs per anchor (MDv5: nc = 3) in the plain forward; the augmented forward and
+ *                               other heads always use the separate decode kernel.  Same statements, bit-identical.
  * Replaces nothing in the reference; the switches exist for measurements and tests. */
 int mdhip_set_option(mdhip_ctx* ctx, const char* name, int value);
 /* time one op in isolation: `iters` back-to-back launches bracketed by events */

@@ -299,11 +299,19 @@ conv_igemm_kernel(const ConvArgs p) {
                 }
             }
             if (p.out_f32) {
+                if (p.dec_pred) {                                   // Detect decode in place (ConvArgs::dec_pred)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int n = n0 + nl0 + j * 16;
-                    if (m_ok && n < p.N)
-                        *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = n0 + nl0 + j * 16;
+                        if (m_ok && n < p.N) mdhip_decode_store(p, m, n, v[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = n0 + nl0 + j * 16;
+                        if (m_ok && n < p.N)
+                            *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    }
                 }
             } else if (p.out_f8) {
                 // e4m3 output (MDHIP_DTYPE_FP8: the hidden tensor of a bottleneck): 4 channels = 4 bytes per lane and

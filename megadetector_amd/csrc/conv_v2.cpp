@@ -483,11 +483,19 @@ conv_v2_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(v[j][0]), "v"(v[j][1]), "v"(v[j][2]), "v"(v[j][3]));
             } else if constexpr (OUT_F32) {
+                if (p.dec_pred) {                                   // Detect decode in place (ConvArgs::dec_pred)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int n = nbase + j * 16;
-                    if (m < p.M && n < p.N)
-                        *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = nbase + j * 16;
+                        if (m < p.M && n < p.N) mdhip_decode_store(p, m, n, v[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = nbase + j * 16;
+                        if (m < p.M && n < p.N)
+                            *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    }
                 }
             } else if constexpr (OUT_F8) {
                 // e4m3 output (MDHIP_DTYPE_FP8: the hidden tensor of a bottleneck): 4 channels = 4 bytes per lane and
@@ -523,13 +531,16 @@ conv_v2_kernel(const ConvArgs p) {
                     auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
                     // row q of the wave now holds channels q*8 .. q*8+7 of the 32 channels of this pair
                     const unsigned off = o_pair + (unsigned)i * o_step + (unsigned)(j * 32);
+                    // (developer variants: PROF & 256 = non-temporal stores, PROF & 512 = write-through stores)
+                    constexpr int ST_AUX = (PROF & 256) ? 2 : ((PROF & 512) ? 16 : 0);
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{t0[0], t1[0], t0[1], t1[1]}, o_rsrc,
-                                                           (int)(npair0 + j * 16 < p.N ? off : kOOB), 0, 0);
+                                                           (int)(npair0 + j * 16 < p.N ? off : kOOB), 0, ST_AUX);
                 }
                 if (FN & 1) {
                     const int j = FN - 1;
+                    constexpr int ST_AUX1 = (PROF & 256) ? 2 : ((PROF & 512) ? 16 : 0);
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{st_pack2(v[j][0], v[j][1]), st_pack2(v[j][2], v[j][3])}, o_rsrc,
-                                                          (int)(nlast < p.N ? o_last + (unsigned)i * o_step : kOOB), 0, 0);
+                                                          (int)(nlast < p.N ? o_last + (unsigned)i * o_step : kOOB), 0, ST_AUX1);
                 }
             }
         }
@@ -584,6 +595,14 @@ conv_v2_kernel(const ConvArgs p) {
         }
     }
 
+    if constexpr ((PROF & 1024) != 0) {
+        // developer variant: the odd M streams of an XCD start p.dev_param x 4096 cycles late, so that the epilogues (store
+        // bursts) of half the CUs fall into the main loops of the other half
+        if ((ms & 1) != 0 && p.dev_param > 0) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)p.dev_param * 4096ull;
+            while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) xa[i] = read_x(0, 0, i);
@@ -745,7 +764,12 @@ conv_v2_kernel(const ConvArgs p) {
     X(24, 320, 160, 4, 2, 2, 1)  \
     X(25, 320, 160, 4, 2, 16, 0) \
     X(26, 320, 160, 4, 2, 6, 0)  \
-    X(27, 320, 160, 4, 2, 64, 0)
+    X(27, 320, 160, 4, 2, 64, 0) \
+    X(28, 320, 160, 4, 2, 256, 0) \
+    X(29, 320, 160, 4, 2, 512, 0) \
+    X(30, 320, 160, 4, 2, 1024, 0) \
+    X(31, 320, 160, 4, 2, 1280, 0) \
+    X(32, 320, 160, 4, 2, 0, 0)
 
 static const ConvCfg g_cfgs2[] = {
 #define X(id, bm, bn, wm, wn)                                                                        \
@@ -771,7 +795,7 @@ static const ConvCfg g_cfgs2[] = {
     MDHIP_CONV2_PROFRING(X)
 #undef X
 };
-constexpr int kNumProf = 13;   // trailing instrumented entries: reachable through conv2_launch only
+constexpr int kNumProf = 18;   // trailing instrumented entries: reachable through conv2_launch only
 
 int conv2_num_cfgs() { return (int)(sizeof(g_cfgs2) / sizeof(g_cfgs2[0])) - kNumProf; }
 const ConvCfg& conv2_cfg(int i) { return g_cfgs2[i]; }

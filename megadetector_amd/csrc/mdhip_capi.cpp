@@ -86,6 +86,9 @@ struct Op {
     double pre_flops = 0;
     // upsample read in place (conv_v2.cpp): an OP_UPSAMPLE whose only reader is the 1x1 conv `up_peer` (and vice versa)
     int up_peer = -1;
+    // Detect: the 1x1 conv of a level and its OP_DECODE (the next op); dec_done = the conv of THIS forward decoded in its
+    // epilogue, the decode op has nothing left to launch
+    bool dec_done = false;
     size_t amax_off = 0;
     // the configuration chosen for the last (n, h, w): the table walk is not repeated on every launch
     int memo_n = 0, memo_h = 0, memo_w = 0, memo_cfg = -1;
@@ -141,6 +144,7 @@ struct mdhip_ctx {
     std::vector<std::vector<int>> fuse_groups;
     bool fuse_enabled = true, fuse_suspended = false;
     bool pair_enabled = true;         // paired taps of a half-full last channel group (conv_v5.cpp); MDHIP_PAIR=0 at create: off
+    bool fuse_decode = true;          // Detect decode in the epilogue of the Detect 1x1 convs (mdhip_set_option "fuse_decode")
     bool letterbox_general = false;   // MDHIP_LETTERBOX_GENERAL at create: never take the streaming-copy letterbox (A/B, tests)
     std::vector<hipEvent_t> events;
     std::vector<mdhip_tuned> tuned;   // measured tile choices (tools/autotune.py)
@@ -1004,6 +1008,32 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             bool from_table = false;
             int cfg = select_cfg(ctx, op, a, n, h, w, &from_table);
             if (cfg < 0) cfg = choose_cfg_for(ctx, a);
+            // Detect decode in this conv's epilogue (mdhip_decode_store): the plain forward of a head with 8 outputs per anchor,
+            // on the two kernel families that take 1x1 / fp32-output ops; the augmented forward (anchors kept / de-scaled /
+            // flipped per pass) and every other head keep the separate decode launch
+            Op* dec = (op.out_f32 && (size_t)(&op - ctx->ops.data()) + 1 < ctx->ops.size() && (&op)[1].kind == OP_DECODE) ? &op + 1 : nullptr;
+            if (dec) dec->dec_done = false;
+            const bool plain_pass = ctx->cur_tta.keep_from == 0 && ctx->cur_tta.keep_to == 0x7fffffff && ctx->cur_tta.out_off == 0 &&
+                                    ctx->cur_tta.scale == 1.0f && ctx->cur_tta.flip_lr == 0;
+            auto decodes_in_place = [&](int c) {
+                return dec && ctx->fuse_decode && !ctx->fuse_suspended && ctx->no == 8 && plain_pass && !ctx->calibrating &&
+                       (c < conv_num_v1_cfgs() || strncmp(conv_api(ctx).cfg(c).name, "v2:", 3) == 0);
+            };
+            auto set_decode = [&](int c) {
+                a.dec_pred = nullptr;
+                if (!decodes_in_place(c)) return;
+                int level_off = 0;
+                for (int l = 0; l < dec->level; ++l) {
+                    const int sl = (int)ctx->strides[l];
+                    level_off += ctx->na * (h / sl) * (w / sl);
+                }
+                a.dec_pred = (float*)(ctx->arena + ctx->pred_off);
+                a.dec_anchors = (const float*)(ctx->warena + ctx->anchors_off) + dec->level * ctx->na * 2;
+                a.dec_stride = ctx->strides[dec->level];
+                a.dec_level_off = level_off;
+                a.dec_n_anchors = ctx->cur_A;
+            };
+            set_decode(cfg);
             hipError_t le = conv_api(ctx).launch(cfg, a, s);
             if (le == hipErrorInvalidValue && from_table && !fused && !up_in_place) {
                 // table entry from another build: not applicable.  Only for an op that is launched as planned: with
@@ -1014,7 +1044,11 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
                 (void)hipGetLastError();
                 cfg = choose_cfg_for(ctx, a);
                 from_table = false;
+                set_decode(cfg);
                 le = conv_api(ctx).launch(cfg, a, s);
+            }
+            if (dec && a.dec_pred && le == hipSuccess) {
+                dec->dec_done = true;
             }
             op.last_cfg = cfg;
             if (op.forced_cfg < 0 && le == hipSuccess) {
@@ -1052,6 +1086,10 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             break;
         }
         case OP_DECODE: {
+            if (op.dec_done) {                     // decoded in the epilogue of the conv in front (this forward)
+                op.bytes = 0;
+                break;
+            }
             const int ny = h / op.in.div, nx = w / op.in.div;
             int level_off = 0;
             for (int l = 0; l < op.level; ++l) {
@@ -1650,6 +1688,7 @@ int mdhip_time_op(mdhip_ctx* ctx, int op, int n, int h, int w, int iters, float*
     ctx->cur_A = num_anchors_for(ctx, h, w);
     // one op in isolation: a bottleneck's two convs as the two launches they are (no fusion)
     struct Suspend { mdhip_ctx* c; Suspend(mdhip_ctx* c_) : c(c_) { c->fuse_suspended = true; } ~Suspend() { c->fuse_suspended = false; } } suspend(ctx);
+    ctx->ops[op].dec_done = false;                                     // (a decode op on its own: launched, whatever the last forward did)
     if (int rc = run_op(ctx, ctx->ops[op], n, h, w, s)) return rc;    // warm
     HIP_TRY(ctx, hipEventRecord(ctx->events[0], s));
     for (int i = 0; i < iters; ++i)
@@ -1843,6 +1882,7 @@ int mdhip_set_fuse(mdhip_ctx* ctx, int on) {
 int mdhip_set_option(mdhip_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return MDHIP_EINVAL;
     if (!strcmp(name, "letterbox_general")) ctx->letterbox_general = value != 0;
+    else if (!strcmp(name, "fuse_decode")) ctx->fuse_decode = value != 0;
     else return fail(ctx, MDHIP_EINVAL, "unknown option '%s'", name);
     drop_graphs(ctx);
     return MDHIP_OK;

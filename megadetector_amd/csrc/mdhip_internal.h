@@ -180,6 +180,14 @@ struct ConvArgs {
     // concat buffer; nullptr = everything from `in`
     const uint16_t* in_up;
     int ld_up, up_slabs;
+    // Detect decode in the epilogue of the Detect 1x1 conv (out_f32 ops of a head with 8 outputs per anchor; conv_igemm.cpp /
+    // conv_v2.cpp): dec_pred != nullptr -> instead of storing its four fp32 logits a lane decodes them (mdhip_decode_store
+    // below: detect_decode_kernel's statements, the same bits) and writes 16 bytes of the prediction row
+    // dec_pred[image][dec_level_off + (anchor * Ho + y) * Wo + x][8]; the logits tensor is then neither written nor read
+    float* dec_pred;
+    const float* dec_anchors;   // device, [na][2]: anchor sizes of this level in pixels
+    float dec_stride;
+    int dec_level_off, dec_n_anchors;
     // floor(2^32 / HoWo), floor(2^32 / Wo) (0xffffffff for a divisor of 1): the tile set-up of the implicit-GEMM kernels
     // splits an output pixel index into (image, row, column) with conv_udiv() instead of two run-time integer
     // divisions per row; filled by conv_launch / conv2_launch (conv_set_rcp), callers leave them alone
@@ -214,6 +222,36 @@ __device__ __forceinline__ void mdhip_bias4(const A& a, const B& b, float (&v)[4
     const mdhip_f32x2 t0 = mdhip_f32x2{a[0], a[1]} + mdhip_f32x2{b[0], b[1]};
     const mdhip_f32x2 t1 = mdhip_f32x2{a[2], a[3]} + mdhip_f32x2{b[2], b[3]};
     v[0] = t0[0]; v[1] = t0[1]; v[2] = t1[0]; v[3] = t1[1];
+}
+// Detect decode (yolov5 Detect.forward, inference): ONE definition for detect_decode_kernel
+// (misc_kernels.cpp) and for the conv epilogues that decode in place -- same statements, no contraction: same bits
+__device__ __forceinline__ float mdhip_sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ void mdhip_decode_box(float l0, float l1, float l2, float l3, int x, int y, float stride, float aw, float ah,
+                                                 float& cx, float& cy, float& bw, float& bh) {
+#pragma clang fp contract(off)
+    const float s0 = mdhip_sigmoid_exact(l0), s1 = mdhip_sigmoid_exact(l1);
+    const float s2 = mdhip_sigmoid_exact(l2), s3 = mdhip_sigmoid_exact(l3);
+    cx = (s0 * 2.0f + ((float)x - 0.5f)) * stride;
+    cy = (s1 * 2.0f + ((float)y - 0.5f)) * stride;
+    const float w2 = s2 * 2.0f, h2 = s3 * 2.0f;
+    bw = (w2 * w2) * aw;
+    bh = (h2 * h2) * ah;
+}
+// a lane's four consecutive logits (channels n .. n + 3 of output pixel m, n a multiple of 4, 8 outputs per anchor) -> its
+// half of the prediction row of anchor n / 8: the box (n mod 8 == 0) or objectness + classes (n mod 8 == 4)
+__device__ __forceinline__ void mdhip_decode_store(const ConvArgs& p, int m, int n, const float (&v)[4]) {
+#pragma clang fp contract(off)
+    const int b = conv_udiv(m, p.HoWo, p.rcp_howo);
+    const int rem = m - b * p.HoWo;
+    const int y = conv_udiv(rem, p.Wo, p.rcp_wo);
+    const int x = rem - y * p.Wo;
+    const int a = n >> 3;
+    const int idx = p.dec_level_off + (a * p.Ho + y) * p.Wo + x;
+    float* o = p.dec_pred + ((size_t)b * p.dec_n_anchors + idx) * 8 + (n & 4);
+    float4 r;
+    if ((n & 4) == 0) mdhip_decode_box(v[0], v[1], v[2], v[3], x, y, p.dec_stride, p.dec_anchors[a * 2 + 0], p.dec_anchors[a * 2 + 1], r.x, r.y, r.z, r.w);
+    else r = make_float4(mdhip_sigmoid_exact(v[0]), mdhip_sigmoid_exact(v[1]), mdhip_sigmoid_exact(v[2]), mdhip_sigmoid_exact(v[3]));
+    *(float4*)o = r;
 }
 __device__ __forceinline__ void mdhip_silu4(float (&v)[4], float neg_log2e = kNegLog2e) {
     const mdhip_f32x2 t0 = silu_f32x2(mdhip_f32x2{v[0], v[1]}, neg_log2e), t1 = silu_f32x2(mdhip_f32x2{v[2], v[3]}, neg_log2e);

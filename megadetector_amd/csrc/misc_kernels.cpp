@@ -467,7 +467,7 @@ hipError_t launch_absmax_view(const uint16_t* in, int ld, int c, long long pixel
 //   y = sigmoid(logits);  xy = (y*2 + grid) * stride, grid = (x-0.5, y-0.5)
 //   wh = (y*2)^2 * anchor_px;  rows ordered (anchor, y, x) inside the level.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_f32(float x) { return mdhip_sigmoid_exact(x); }
 
 // one thread per (image, anchor, pixel): the general form (any number of anchors / outputs)
 __global__ void __launch_bounds__(256)

@@ -357,6 +357,64 @@ def test_strip_kernel_is_bit_identical_to_the_row_segment_kernel(dtype):
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_detect_decode_in_the_conv_epilogue_is_bit_identical_to_the_decode_kernel(dtype):
+    """[r6] the Detect decode (yolov5 Detect.forward behind reference pytorch_detector.py:1313) runs in the epilogue of each
+    level's 1x1 conv (mdhip_decode_store: the decode kernel's statements) -- no fp32 logits tensor, four launches fewer:
+    the same bits as conv + detect_decode_kernel (mdhip_set_option "fuse_decode" 0), with the Detect convs on the table's
+    tiles and forced onto each of the two kernel families that take them (conv_igemm.cpp, conv_v2.cpp), ragged M tiles,
+    several images per batch; the augmented forward keeps the separate kernel and its bits; a head with another number
+    of outputs per anchor (nc = 5) is never fused."""
+    from megadetector_amd import weights_io, yolo_yaml
+    from megadetector_amd.hip_backend import HipContext
+    W = weights_io.synthetic_weights(yolo_yaml.YOLOV5S6_TEST, seed=3)
+    for (n, hh, ww) in ((2, 384, 640), (3, 192, 320), (1, 640, 640)):
+        ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
+        try:
+            imgs = PU.structured_images(n, hh, ww, seed=hh + ww)
+            ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            infos = ctx.op_infos()
+            det_convs = [o['op'] for o in infos if o['kind'] == 0 and 'Detect' in o['name']]
+            decodes = [o['op'] for o in infos if o['kind'] == 3]
+            assert len(det_convs) == 4 and decodes == [c + 1 for c in det_convs]
+            v1 = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == '128x64/2x2/s2/p0'][0]
+            v2 = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c) == 'v2:128x80/4x1'][0]
+            for forced in (None, v1, v2):
+                for op in det_convs:
+                    ctx.set_op_cfg(op, -1 if forced is None else forced)
+                ctx.set_option('fuse_decode', 0)
+                ctx.forward(n, hh, ww)
+                ref = ctx.read_predictions(n).copy()
+                assert all(ctx.op_infos()[d]['bytes'] > 0 for d in decodes)           # four decode launches
+                ctx.forward_tta(n, hh, ww)
+                ref_tta = ctx.read_predictions(n).copy()
+                ctx.set_option('fuse_decode', 1)
+                ctx.forward(n, hh, ww)
+                assert all(ctx.op_infos()[d]['bytes'] == 0 for d in decodes)          # none: decoded in the convs' epilogues
+                np.testing.assert_array_equal(ctx.read_predictions(n), ref)
+                ctx.forward(n, hh, ww)                                                # the other prediction buffer
+                np.testing.assert_array_equal(ctx.read_predictions(n), ref)
+                ctx.forward_tta(n, hh, ww)                                            # augmented: separate decode, same bits
+                np.testing.assert_array_equal(ctx.read_predictions(n), ref_tta)
+                if n > 1:                                                             # batch invariance while fused
+                    ctx.preprocess([imgs[n - 1]], _identity_geoms([imgs[n - 1]]), hh, ww)
+                    ctx.forward(1, hh, ww)
+                    np.testing.assert_array_equal(ctx.read_predictions(1)[0], ref[n - 1])
+                    ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+        finally:
+            ctx.close()
+    # nc = 5: 10 outputs per anchor, a lane's four channels straddle anchors -> the decode kernel, whatever the switch says
+    W5 = weights_io.synthetic_weights(yolo_yaml.YOLOV5N_P5_TEST, seed=2)
+    ctx = HipContext(W5, device=0, dtype=dtype, max_batch=2, max_h=256, max_w=256)
+    try:
+        imgs = PU.structured_images(2, 256, 256, seed=9)
+        ctx.preprocess(imgs, _identity_geoms(imgs), 256, 256)
+        ctx.forward(2, 256, 256)
+        assert all(o['bytes'] > 0 for o in ctx.op_infos() if o['kind'] == 3)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_fused_bottleneck_is_bit_identical_to_the_two_launches(dtype):
     """conv_v5c.cpp's fused kernel (1x1 -> hidden tensor in LDS -> 3x3 + residual, the block ping-ponging between its two
     buffers) against the same four bottlenecks as 1x1 and strip-3x3 launches (mdhip_set_fuse 0): same arithmetic, same
