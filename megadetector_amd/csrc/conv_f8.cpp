@@ -478,9 +478,17 @@ conv_f8_kernel(const ConvArgs p) {
     X(3, 128, 80, 4, 1, 0)  \
     X(4, 64, 160, 2, 2, 0)  \
     X(5, 64, 80, 2, 1, 0)
+// (PROF bits: 1 = s_memtime stamps, 2 = no stores, 4 = no SiLU, 16 = no LDS-DMA in the steady state)
 #define MDHIP_CONV8_PROF(X) \
     X(6, 128, 160, 2, 2, 1)  \
-    X(7, 128, 160, 2, 2, 16)
+    X(7, 128, 160, 2, 2, 16) \
+    X(8, 128, 160, 2, 2, 2)  \
+    X(9, 128, 160, 2, 2, 6)  \
+    X(10, 128, 160, 2, 2, 22) \
+    X(11, 256, 160, 4, 2, 1) \
+    X(12, 256, 160, 4, 2, 16) \
+    X(13, 256, 160, 4, 2, 2) \
+    X(14, 256, 160, 4, 2, 22)
 
 static const ConvCfg g_cfgs8[] = {
 #define X(id, bm, bn, wm, wn, prof)                                                                   \
@@ -489,7 +497,7 @@ static const ConvCfg g_cfgs8[] = {
     MDHIP_CONV8_CFGS(X) MDHIP_CONV8_PROF(X)
 #undef X
 };
-constexpr int kNumProf8 = 2;
+constexpr int kNumProf8 = 9;
 
 int conv8_num_cfgs() { return (int)(sizeof(g_cfgs8) / sizeof(g_cfgs8[0])) - kNumProf8; }
 const ConvCfg& conv8_cfg(int i) { return g_cfgs8[i]; }

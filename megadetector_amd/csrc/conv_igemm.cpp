@@ -81,7 +81,10 @@ constexpr int conv_waves_per_simd(int bm, int bn, int nw, int ns) {
 // FP = 1: fragment prefetch -- the LDS reads of the next 32-deep half slab are issued before the
 // MFMAs of the current one (two register sets), so ds_read latency hides under the matrix pipe
 // instead of in front of it; needs NS >= 3 because the next slab must already have landed.
-template <int BM, int BN, int WM, int WN, int NS, int FP>
+// DEC = 1: the instantiation for the Detect 1x1 convs that decode in their epilogue (ConvArgs::dec_pred, mdhip_decode_store).  Its own
+// instantiation, of the narrow tiles only: as a run-time branch the decode path (expf, a division, the grid arithmetic) cost every
+// instantiation 10 - 24 registers and put scratch memory into the widest tiles of conv_v2.cpp (measured in the ISA, round 6).
+template <int BM, int BN, int WM, int WN, int NS, int FP, int DEC = 0>
 __global__ void __launch_bounds__(WM * WN * 64, conv_waves_per_simd(BM, BN, WM * WN, NS))
 conv_igemm_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource
@@ -298,20 +301,18 @@ conv_igemm_kernel(const ConvArgs p) {
                     }
                 }
             }
-            if (p.out_f32) {
-                if (p.dec_pred) {                                   // Detect decode in place (ConvArgs::dec_pred)
+            if constexpr (DEC != 0) {                               // Detect decode in place (ConvArgs::dec_pred)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        const int n = n0 + nl0 + j * 16;
-                        if (m_ok && n < p.N) mdhip_decode_store(p, m, n, v[j]);
-                    }
-                } else {
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + nl0 + j * 16;
+                    if (m_ok && n < p.N) mdhip_decode_store(p, m, n, v[j]);
+                }
+            } else if (p.out_f32) {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        const int n = n0 + nl0 + j * 16;
-                        if (m_ok && n < p.N)
-                            *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
-                    }
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + nl0 + j * 16;
+                    if (m_ok && n < p.N)
+                        *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 }
             } else if (p.out_f8) {
                 // e4m3 output (MDHIP_DTYPE_FP8: the hidden tensor of a bottleneck): 4 channels = 4 bytes per lane and
@@ -482,9 +483,31 @@ constexpr int kNumV1 = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
 int conv_num_v1_cfgs() { return kNumV1; }
 
 namespace {
+// the first-generation configurations that exist in a decoding instantiation (DEC): the narrow tiles a 24-channel op is given
+constexpr bool v1_decodes(int bn) { return bn <= 80; }
+template <int BM, int BN, int WM, int WN, int NS, int FP>
+hipError_t v1_set_lds(int lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, NS, FP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (v1_decodes(BN)) {
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, NS, FP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    return e;
+}
+template <int BM, int BN, int WM, int WN, int NS, int FP>
+hipError_t v1_launch(const ConvArgs& p, dim3 grid, size_t lds, hipStream_t s) {
+    if (p.dec_pred) {
+        if constexpr (v1_decodes(BN)) {
+            hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, FP, 1>), grid, dim3(WM * WN * 64), lds, s, p);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, FP>), grid, dim3(WM * WN * 64), lds, s, p);
+    return hipGetLastError();
+}
 bool conv2_supports_l(int cfg, const ConvArgs& a) {
     if (conv2_cfg_is_ring(cfg) && !(conv2_is_pointwise(a) && a.k_pad >= 3 * 64)) return false;
-    if (conv2_cfg_is_pf(cfg) && !conv2_pf_supports(a)) return false;
     return conv2_supports(a) && (a.in_up == nullptr || cfg == 0);                    // in_up: 160x160 only
 }
 // one row per kernel family after the first: local configuration ids [0, num()), developer variants
@@ -540,8 +563,18 @@ bool conv_cfg_is_bitwise_family(int cfg) {
     return f ? f->bitwise : true;
 }
 
+// (a.dec_pred: the op decodes in its epilogue -- only the configurations with such an instantiation take it)
+bool conv_cfg_decodes(int cfg) {
+    if (cfg < 0 || cfg >= conv_num_cfgs()) return false;
+    if (cfg < kNumV1) return v1_decodes(g_cfgs[cfg].bn);
+    int l = 0;
+    const Family* f = find_family(cfg, &l);
+    return f == &g_fams[0] && conv2_cfg_decodes(l);
+}
+
 bool conv_supports(int cfg, const ConvArgs& a) {
     if (cfg < 0 || cfg >= conv_num_cfgs()) return false;
+    if (a.dec_pred && !(conv_cfg_decodes(cfg) && a.out_f32 && (a.N % 8) == 0)) return false;
     if (cfg < kNumV1) return !a.in_f8;                              // the first-generation kernel takes every 16-bit op
     int l = 0;
     const Family* f = find_family(cfg, &l);
@@ -551,10 +584,8 @@ bool conv_supports(int cfg, const ConvArgs& a) {
 
 hipError_t conv_init() {
     hipError_t e = hipSuccess;
-#define X(id, bm, bn, wm, wn, ns, fp)                                                                \
-    if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<bm, bn, wm, wn, ns, fp>,                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs[id].lds_bytes);
+#define X(id, bm, bn, wm, wn, ns, fp) \
+    if (e == hipSuccess) e = v1_set_lds<bm, bn, wm, wn, ns, fp>((int)g_cfgs[id].lds_bytes);
     MDHIP_CONV_CFGS(X)
 #undef X
     for (int f = 0; f < kNumFams && e == hipSuccess; ++f) e = g_fams[f].init();
@@ -586,16 +617,14 @@ hipError_t conv_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     p.tiles_per_xcd = (p.tiles_m + 7) / 8;
     p.m_streams = std::max(1, std::min(p.tiles_per_xcd, (32 * c.blocks_per_cu) / p.tiles_n));
     const dim3 grid((unsigned)(8 * p.tiles_n * p.m_streams));
+    if (p.dec_pred && !conv_supports(cfg, p)) return hipErrorInvalidValue;
     switch (cfg) {
-#define X(id, bm, bn, wm, wn, ns, fp)                                                               \
-    case id:                                                                                      \
-        hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, ns, fp>), grid, dim3((wm) * (wn) * 64), \
-                           c.lds_bytes, s, p);                                                    \
-        break;
+#define X(id, bm, bn, wm, wn, ns, fp) \
+    case id: return v1_launch<bm, bn, wm, wn, ns, fp>(p, grid, c.lds_bytes, s);
         MDHIP_CONV_CFGS(X)
 #undef X
     }
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 }  // namespace MDHIP_ST

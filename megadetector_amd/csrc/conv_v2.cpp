@@ -74,32 +74,20 @@ constexpr int v2_waves_per_simd(int bm, int bn, int nw) {
 // a ring of three beside the weight tile's ring of two -- a short-K pointwise layer is bound by one memory round trip per K step
 // (a two-stage ring prefetches ONE step ahead), its weights come from L2 in a third of the time its activations take from the
 // memory side, so the LDS a third weight stage would need buys more as activation lead (DESIGN.md section 5 [r4])
-// PFW = 1 (pointwise ring instantiations only): the workgroup's LAST wave loads nothing and instead touches, PF_AHEAD K steps
-// ahead of the loaders, one dword of every 128-byte line of the activation slabs to come (plain buffer loads into a register
-// nobody reads), so that the lines are in the XCD's L2 when the loaders' LDS-DMA pieces ask for them.  Why: the N tiles of an
-// M stream run on neighbouring CUs of one XCD and request the SAME activation lines at the same time, so of the ~80 KiB of
-// activation pieces a workgroup keeps in flight only 1 / tiles_n are distinct HBM requests -- 20 KiB per CU at N = 640, a
-// quarter of what the memory side needs in flight to stream at its rate (Little's law; the N = 160 layers, which share
-// nothing, run at 4.1 TB/s, the N = 640 ones at 2.6).  L2 has the capacity the LDS lacks.  The prefetcher must be a wave of
-// its own: loads return in order within a wave, so one long-latency touch in a loader's queue would hold up every counted
-// wait behind it.  The CUs of an M stream split the lines between them (64-row chunk c of slab k: tile_n == (c + k) mod
-// tiles_n).  Same loads into LDS, same MFMA chain: bit-identical to the instantiation without it.
-template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false, int PW = 0, int RA = 2, int PFW = 0>
+// DEC = 1: the instantiation for the Detect 1x1 convs that decode in their epilogue (ConvArgs::dec_pred; conv_igemm.cpp on why it is one)
+template <int BM, int BN, int WM, int WN, int PROF = 0, bool UP = false, int PW = 0, int RA = 2, int DEC = 0>
 __global__ void __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BM, BN, WM * WN))
 conv_v2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN;
-    constexpr int LW = PFW ? NW - 1 : NW;                 // waves that issue LDS-DMA pieces
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;     // 1 KiB pieces (8 rows x 128 B) of the activation / weight tile
-    constexpr int A_PER = (A_INSTR + LW - 1) / LW, B_PER = (B_INSTR + LW - 1) / LW;
-    constexpr bool A_RAGGED = (A_INSTR % LW) != 0;        // the last piece exists only on the first waves
-    constexpr bool B_RAGGED = (B_INSTR % LW) != 0;
-    static_assert(PFW || (BM / 8) % NW == 0, "the activation tile must split evenly over the waves");
+    constexpr int B_INSTR = BN / 8;                       // 1 KiB pieces (8 rows x 128 B) of the weight tile
+    constexpr int A_PER = BM / 8 / NW, B_PER = (B_INSTR + NW - 1) / NW;
+    constexpr bool B_RAGGED = (B_INSTR % NW) != 0;        // the last piece exists only on the first waves
+    static_assert((BM / 8) % NW == 0, "the activation tile must split evenly over the waves");
     static_assert(RA == 2 || (RA == 3 && PW != 0 && !UP), "the three-stage activation ring is a pointwise instantiation");
-    static_assert(!PFW || (RA == 3 && NW == 8 && (BM % 64) == 0), "the prefetch wave belongs to the 8-wave pointwise ring tiles");
     // byte offsets of activation stage sa / weight stage sb
     auto a_stage = [](int sa) __attribute__((always_inline)) { return RA == 2 ? sa * STAGE : sa * A_BYTES; };
     auto b_stage = [](int sb) __attribute__((always_inline)) { return RA == 2 ? sb * STAGE + A_BYTES : RA * A_BYTES + sb * B_BYTES; };
@@ -112,7 +100,6 @@ conv_v2_kernel(const ConvArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    [[maybe_unused]] const bool is_pf = PFW != 0 && wave == NW - 1;      // (wave-uniform: a scalar branch)
 
     // ---- persistent streams (see conv_igemm.cpp): block b runs on XCD b % 8 ---------------------
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -137,7 +124,7 @@ conv_v2_kernel(const ConvArgs p) {
     unsigned b_off[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-        const int row = (i * LW + wave) * 8 + lr;
+        const int row = (i * NW + wave) * 8 + lr;
         b_off[i] = (n0 + row < p.n_rows) ? (unsigned)(row * p.k_pad + jj * 8) * 2u : kOOB;
     }
 
@@ -178,7 +165,7 @@ conv_v2_kernel(const ConvArgs p) {
                                                        (int)(left > 0x7fffffffLL ? 0x7fffffffLL : left), 0x00020000);
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
-                const int row = (i * LW + wave) * 8 + lr;
+                const int row = (i * NW + wave) * 8 + lr;
                 a_off[i] = (unsigned)(row * p.ld_in * 2 + jj * 16);
                 a_mask[i] = 1u;
             }
@@ -273,10 +260,6 @@ conv_v2_kernel(const ConvArgs p) {
     // one LDS-DMA piece of the loader's current slab into stage `buf`
     auto dma_a = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
-        if constexpr (PFW != 0) {
-            if (is_pf) return;                                                   // wave-uniform
-            if (A_RAGGED && i == A_PER - 1 && wave >= A_INSTR % LW) return;     // wave-uniform
-        }
         if constexpr (UP) {
             if (l_kt < up_slabs) {                                               // wave-uniform
                 MDHIP_DMA16(u_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, (a_mask[i] & tapbit) ? u_off[i] : kOOB, l_kt * 128);
@@ -284,7 +267,7 @@ conv_v2_kernel(const ConvArgs p) {
             }
         }
         if constexpr (PW) {
-            MDHIP_DMA16(a_rsrc, smem + a_stage(buf) + (i * LW + wave) * 1024, a_off[i], l_kt * 128);
+            MDHIP_DMA16(a_rsrc, smem + a_stage(buf) + (i * NW + wave) * 1024, a_off[i], l_kt * 128);
         } else {
             const unsigned voff = (a_mask[i] & tapbit) ? a_off[i] + tapoff : kOOB;
             MDHIP_DMA16(a_rsrc, smem + buf * STAGE + (i * NW + wave) * 1024, voff, 0);
@@ -292,56 +275,10 @@ conv_v2_kernel(const ConvArgs p) {
     };
     auto dma_b = [&](int buf, int i) __attribute__((always_inline)) {
         if constexpr ((PROF & 16) != 0) return;
-        if constexpr (PFW != 0) {
-            if (is_pf) return;                                               // wave-uniform
-        }
-        if (B_RAGGED && i == B_PER - 1 && wave >= B_INSTR % LW) return;     // wave-uniform
+        if (B_RAGGED && i == B_PER - 1 && wave >= B_INSTR % NW) return;     // wave-uniform
         // (PW: after the stream's last slab the loader re-reads slabs of the last tile into stages nobody reads)
         const unsigned voff = (PW || l_live) ? b_off[i] : kOOB;
-        MDHIP_DMA16(b_rsrc, smem + b_stage(buf) + (i * LW + wave) * 1024, voff, (RA == 3 ? lb_kt : l_kt) * 128);
-    };
-
-    // ---- prefetch wave (PFW): position PF_AHEAD slabs ahead of the activation loader, one dword per 128-byte line ------------
-    // The touches go through a descriptor that covers exactly the tensor (rows behind the last pixel are not fetched: the
-    // row part of the address is in the vector offset, which the range check sees) and land in v255, a register the kernel
-    // does not use (checked in the ISA; every statement names it as clobbered).  Nothing ever waits for them except the
-    // flow-control wait below and the drain at the kernel's end.
-    typedef int pf_i32x4 __attribute__((ext_vector_type(4)));
-    [[maybe_unused]] int pf_tile = first_tile, pf_kt = 0, pf_phase = 0;
-    [[maybe_unused]] bool pf_live = PFW != 0;
-    [[maybe_unused]] const unsigned pf_pitch = (unsigned)p.ld_in * 2u;
-    [[maybe_unused]] const unsigned pf_lane = (unsigned)lane * pf_pitch;
-    [[maybe_unused]] pf_i32x4 pf_rsrc = {0, 0, 0, 0};
-    if constexpr (PFW != 0) {
-        const unsigned long long pa = (unsigned long long)p.in;
-        pf_rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pa);
-        pf_rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(pa >> 32));
-        pf_rsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)p.M * pf_pitch));      // (conv2_launch: < 2^32 bytes)
-        pf_rsrc[3] = 0x00020000;
-    }
-    auto pf_advance = [&]() __attribute__((always_inline)) {
-        pf_phase = (pf_phase + 1 == p.tiles_n) ? 0 : pf_phase + 1;
-        if (++pf_kt == KT) {
-            pf_kt = 0;
-            pf_phase = 0;
-            if (pf_tile == last_tile) pf_live = false;
-            else pf_tile += tile_step;
-        }
-    };
-    // this CU's share of slab (pf_tile, pf_kt): the 64-row chunks c with (c + pf_kt) mod tiles_n == tile_n
-    auto pf_issue = [&]() __attribute__((always_inline)) {
-        if constexpr (PFW != 0) {
-            if (pf_live) {
-                int c0 = tile_n - pf_phase;
-                c0 = c0 < 0 ? c0 + p.tiles_n : c0;
-                const unsigned so = (unsigned)pf_kt * 128u;
-                for (int c = c0; c < BM / 64; c += p.tiles_n) {
-                    const unsigned vo = pf_lane + (unsigned)(pf_tile * BM + c * 64) * pf_pitch;
-                    asm volatile("s_nop 4\n\tbuffer_load_dword v255, %0, %1, %2 offen" ::"v"(vo), "s"(pf_rsrc), "s"(so) : "v255", "memory");
-                }
-            }
-            pf_advance();
-        }
+        MDHIP_DMA16(b_rsrc, smem + b_stage(buf) + (i * NW + wave) * 1024, voff, (RA == 3 ? lb_kt : l_kt) * 128);
     };
 
     // ---- fragment reads ---------------------------------------------------------------------------
@@ -482,20 +419,18 @@ conv_v2_kernel(const ConvArgs p) {
             if constexpr ((PROF & 2) != 0) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(v[j][0]), "v"(v[j][1]), "v"(v[j][2]), "v"(v[j][3]));
+            } else if constexpr (OUT_F32 && DEC != 0) {            // Detect decode in place (ConvArgs::dec_pred)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = nbase + j * 16;
+                    if (m < p.M && n < p.N) mdhip_decode_store(p, m, n, v[j]);
+                }
             } else if constexpr (OUT_F32) {
-                if (p.dec_pred) {                                   // Detect decode in place (ConvArgs::dec_pred)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        const int n = nbase + j * 16;
-                        if (m < p.M && n < p.N) mdhip_decode_store(p, m, n, v[j]);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        const int n = nbase + j * 16;
-                        if (m < p.M && n < p.N)
-                            *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
-                    }
+                for (int j = 0; j < FN; ++j) {
+                    const int n = nbase + j * 16;
+                    if (m < p.M && n < p.N)
+                        *(float4*)((float*)p.out + (size_t)m * p.ld_out + n) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 }
             } else if constexpr (OUT_F8) {
                 // e4m3 output (MDHIP_DTYPE_FP8: the hidden tensor of a bottleneck): 4 channels = 4 bytes per lane and
@@ -531,22 +466,22 @@ conv_v2_kernel(const ConvArgs p) {
                     auto t1 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
                     // row q of the wave now holds channels q*8 .. q*8+7 of the 32 channels of this pair
                     const unsigned off = o_pair + (unsigned)i * o_step + (unsigned)(j * 32);
-                    // (developer variants: PROF & 256 = non-temporal stores, PROF & 512 = write-through stores)
-                    constexpr int ST_AUX = (PROF & 256) ? 2 : ((PROF & 512) ? 16 : 0);
+                    // (round 6, measured and not kept: non-temporal stores +- 0 .. - 19 %, write-through stores - 17 .. - 22 %,
+                    // profiles/r6_pointwise_experiments.txt)
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{t0[0], t1[0], t0[1], t1[1]}, o_rsrc,
-                                                           (int)(npair0 + j * 16 < p.N ? off : kOOB), 0, ST_AUX);
+                                                           (int)(npair0 + j * 16 < p.N ? off : kOOB), 0, 0);
                 }
                 if (FN & 1) {
                     const int j = FN - 1;
-                    constexpr int ST_AUX1 = (PROF & 256) ? 2 : ((PROF & 512) ? 16 : 0);
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{st_pack2(v[j][0], v[j][1]), st_pack2(v[j][2], v[j][3])}, o_rsrc,
-                                                          (int)(nlast < p.N ? o_last + (unsigned)i * o_step : kOOB), 0, ST_AUX1);
+                                                          (int)(nlast < p.N ? o_last + (unsigned)i * o_step : kOOB), 0, 0);
                 }
             }
         }
     };
     auto epilogue = [&](int tile_m) {
         if constexpr ((PROF & 8) != 0) __builtin_amdgcn_s_setprio(3);
+        if constexpr (DEC != 0) { epilogue_t(tile_m, std::false_type{}, std::true_type{}, std::false_type{}); return; }
         if (p.out_f32) epilogue_t(tile_m, std::false_type{}, std::true_type{}, std::false_type{});
         else if (p.out_f8) epilogue_t(tile_m, std::false_type{}, std::false_type{}, std::true_type{});
         else if (p.res) epilogue_t(tile_m, std::true_type{}, std::false_type{}, std::false_type{});
@@ -585,24 +520,6 @@ conv_v2_kernel(const ConvArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (PFW != 0) {
-        if (is_pf) {
-            // slabs 0 .. 2 are on their way (prologue above); the touches start at slab 3 and run `ahead` slabs in front of the
-            // loaders from here on (p.dev_param: developer override of the distance)
-            const int ahead = p.dev_param > 0 ? p.dev_param : 6;
-            for (int i = 0; i < 3; ++i) pf_advance();
-            for (int i = 0; i < ahead; ++i) pf_issue();
-        }
-    }
-
-    if constexpr ((PROF & 1024) != 0) {
-        // developer variant: the odd M streams of an XCD start p.dev_param x 4096 cycles late, so that the epilogues (store
-        // bursts) of half the CUs fall into the main loops of the other half
-        if ((ms & 1) != 0 && p.dev_param > 0) {
-            const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)p.dev_param * 4096ull;
-            while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) xa[i] = read_x(0, 0, i);
@@ -651,13 +568,7 @@ conv_v2_kernel(const ConvArgs p) {
         // slab step+1 has landed (this wave's pieces), stage `cur` is fully in registers
         // (RA == 3: the activation pieces of slab step+2, issued BEHIND the weight pieces of slab step+1 in the half step before,
         // may still be in flight: loads complete in order)
-        if constexpr (PFW != 0) {
-            // (the prefetch wave waits for none of its touches -- only the flow control of its queue; a loader wave for all
-            // but the activation pieces it issued last, one fewer on the waves without a last piece)
-            if (is_pf) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
-            else if (A_RAGGED && wave >= A_INSTR % LW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_PER - 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_PER) : "memory");
-        } else if constexpr (RA == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_PER) : "memory");
+        if constexpr (RA == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         stamp(1);
         __builtin_amdgcn_s_barrier();
@@ -697,9 +608,6 @@ conv_v2_kernel(const ConvArgs p) {
 
         stamp(3);
         advance();
-        if constexpr (PFW != 0) {
-            if (is_pf) pf_issue();
-        }
         if constexpr (RA == 3) {
             lb_advance();
             ca = ca == 2 ? 0 : ca + 1;
@@ -712,7 +620,6 @@ conv_v2_kernel(const ConvArgs p) {
         }
         stamp(5);
     }
-    if constexpr (PFW != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no touch may land after the wave has gone)
     if constexpr ((PROF & 1) != 0) {
         if (lane == 0 && p.dbg) {
             unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
@@ -744,32 +651,26 @@ conv_v2_kernel(const ConvArgs p) {
     X(10, 64, 160, 1, 2)    \
     X(11, 320, 160, 4, 2)   \
     X(12, 256, 160, 4, 2)
-// the same with the prefetch wave (PFW = 1, "a3p"): id, BM, BN, WM, WN
-#define MDHIP_CONV2_RINGPF(X) \
-    X(13, 320, 160, 4, 2)   \
-    X(14, 256, 160, 4, 2)
+// the configurations that also exist as a decoding instantiation (DEC = 1; conv2_cfg_decodes): id, BM, BN, WM, WN
+#define MDHIP_CONV2_DEC(X) \
+    X(0, 160, 160, 2, 2)   \
+    X(2, 160, 80, 2, 1)    \
+    X(3, 128, 80, 4, 1)    \
+    X(8, 320, 160, 4, 2)
 // id, BM, BN, WM, WN, PROF bits (1 = s_memtime stamps, 2 = no stores, 4 = no SiLU)
 #define MDHIP_CONV2_PROF(X) \
-    X(15, 160, 160, 2, 2, 1)  \
-    X(16, 320, 160, 4, 2, 1) \
-    X(17, 160, 160, 2, 2, 54) \
-    X(18, 320, 160, 4, 2, 22) \
-    X(19, 320, 160, 4, 2, 16) \
-    X(20, 160, 160, 2, 2, 16)
-// pointwise ring instantiation (PW = 1, RA = 3) with PROF bits, with / without the prefetch wave: id, BM, BN, WM, WN, PROF, PFW
+    X(13, 160, 160, 2, 2, 1)  \
+    X(14, 320, 160, 4, 2, 1) \
+    X(15, 160, 160, 2, 2, 54) \
+    X(16, 320, 160, 4, 2, 22) \
+    X(17, 320, 160, 4, 2, 16) \
+    X(18, 160, 160, 2, 2, 16)
+// the pointwise ring instantiation (PW = 1, RA = 3) with PROF bits (round 6: where a 1x1 launch's time goes): id, BM, BN, WM, WN, PROF
 #define MDHIP_CONV2_PROFRING(X) \
-    X(21, 320, 160, 4, 2, 1, 0)  \
-    X(22, 320, 160, 4, 2, 1, 1)  \
-    X(23, 320, 160, 4, 2, 2, 0)  \
-    X(24, 320, 160, 4, 2, 2, 1)  \
-    X(25, 320, 160, 4, 2, 16, 0) \
-    X(26, 320, 160, 4, 2, 6, 0)  \
-    X(27, 320, 160, 4, 2, 64, 0) \
-    X(28, 320, 160, 4, 2, 256, 0) \
-    X(29, 320, 160, 4, 2, 512, 0) \
-    X(30, 320, 160, 4, 2, 1024, 0) \
-    X(31, 320, 160, 4, 2, 1280, 0) \
-    X(32, 320, 160, 4, 2, 0, 0)
+    X(19, 320, 160, 4, 2, 1)  \
+    X(20, 320, 160, 4, 2, 2)  \
+    X(21, 320, 160, 4, 2, 16) \
+    X(22, 320, 160, 4, 2, 64)
 
 static const ConvCfg g_cfgs2[] = {
 #define X(id, bm, bn, wm, wn)                                                                        \
@@ -781,21 +682,17 @@ static const ConvCfg g_cfgs2[] = {
     {bm, bn, (wm) * (wn) * 64, (size_t)v2_ring_lds_bytes(bm, bn), 163840 / v2_ring_lds_bytes(bm, bn) >= 2 ? 2 : 1, "v2:" #bm "x" #bn "/" #wm "x" #wn "/a3"},
     MDHIP_CONV2_RING(X)
 #undef X
-#define X(id, bm, bn, wm, wn)                                                                        \
-    {bm, bn, (wm) * (wn) * 64, (size_t)v2_ring_lds_bytes(bm, bn), 163840 / v2_ring_lds_bytes(bm, bn) >= 2 ? 2 : 1, "v2:" #bm "x" #bn "/" #wm "x" #wn "/a3p"},
-    MDHIP_CONV2_RINGPF(X)
-#undef X
 #define X(id, bm, bn, wm, wn, prof)                                                                  \
     {bm, bn, (wm) * (wn) * 64, (size_t)v2_lds_bytes(bm, bn), v2_blocks_per_cu(bm, bn, (wm) * (wn)), \
      "v2prof" #prof ":" #bm "x" #bn "/" #wm "x" #wn},
     MDHIP_CONV2_PROF(X)
 #undef X
-#define X(id, bm, bn, wm, wn, prof, pfw)                                                             \
-    {bm, bn, (wm) * (wn) * 64, (size_t)v2_ring_lds_bytes(bm, bn), 1, "v2prof" #prof ":" #bm "x" #bn "/" #wm "x" #wn "/a3/pf" #pfw},
+#define X(id, bm, bn, wm, wn, prof)                                                                  \
+    {bm, bn, (wm) * (wn) * 64, (size_t)v2_ring_lds_bytes(bm, bn), 1, "v2prof" #prof ":" #bm "x" #bn "/" #wm "x" #wn "/a3"},
     MDHIP_CONV2_PROFRING(X)
 #undef X
 };
-constexpr int kNumProf = 18;   // trailing instrumented entries: reachable through conv2_launch only
+constexpr int kNumProf = 10;   // trailing instrumented entries: reachable through conv2_launch only
 
 int conv2_num_cfgs() { return (int)(sizeof(g_cfgs2) / sizeof(g_cfgs2[0])) - kNumProf; }
 const ConvCfg& conv2_cfg(int i) { return g_cfgs2[i]; }
@@ -823,26 +720,23 @@ hipError_t conv2_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
     MDHIP_CONV2_RING(X)
 #undef X
-#define X(id, bm, bn, wm, wn)                                                                        \
-    if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, 1, 3, 1>,       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes); \
-    if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, 2, 3, 1>,       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
-    MDHIP_CONV2_RINGPF(X)
-#undef X
 #define X(id, bm, bn, wm, wn, prof)                                                                  \
     if (e == hipSuccess)                                                                           \
         e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, prof>,                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
     MDHIP_CONV2_PROF(X)
 #undef X
-#define X(id, bm, bn, wm, wn, prof, pfw)                                                             \
+#define X(id, bm, bn, wm, wn, prof)                                                                  \
     if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, prof, false, 1, 3, pfw>,  \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, prof, false, 1, 3>,       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
     MDHIP_CONV2_PROFRING(X)
+#undef X
+#define X(id, bm, bn, wm, wn)                                                                        \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void*)conv_v2_kernel<bm, bn, wm, wn, 0, false, 1, 2, 1>,       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_cfgs2[id].lds_bytes);
+    MDHIP_CONV2_DEC(X)
 #undef X
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_v2_kernel<160, 160, 2, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -852,9 +746,9 @@ hipError_t conv2_init() {
 
 // (the configurations with a three-stage activation ring: 1x1 / stride 1 / unpadded launches only, at least three K slabs)
 bool conv2_cfg_is_ring(int cfg) { return cfg >= 9 && cfg < conv2_num_cfgs(); }
-// (the configurations with the prefetch wave: the whole input tensor behind one buffer descriptor)
-bool conv2_cfg_is_pf(int cfg) { return cfg >= 13 && cfg < conv2_num_cfgs(); }
-bool conv2_pf_supports(const ConvArgs& a) { return (long long)a.M * a.ld_in * 2 < 0xffffff00LL; }
+// the configurations with a decoding instantiation (pointwise, channel count a multiple of 64): the tiles the tables give the
+// 24-channel Detect convs
+bool conv2_cfg_decodes(int cfg) { return cfg == 0 || cfg == 2 || cfg == 3 || cfg == 8; }
 bool conv2_is_pointwise(const ConvArgs& a) {
     return a.ntaps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.in_up == nullptr;
 }
@@ -883,6 +777,18 @@ hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
     }
     // 1x1 / stride 1 / unpadded: the instantiation whose tile set-up needs no divisions (same loads, same results)
     const bool pw = a.ntaps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
+    if (a.dec_pred) {                                  // Detect conv that decodes in its epilogue
+        if (!pw || (a.C8 & 7) != 0 || !a.out_f32 || !conv2_cfg_decodes(cfg)) return hipErrorInvalidValue;
+        switch (cfg) {
+#define X(id, bm, bn, wm, wn)                                                                        \
+    case id:                                                                                       \
+        hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, 1, 2, 1>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        break;
+            MDHIP_CONV2_DEC(X)
+#undef X
+        }
+        return hipGetLastError();
+    }
     switch (cfg) {
 #define X(id, bm, bn, wm, wn)                                                                        \
     case id:                                                                                       \
@@ -900,24 +806,16 @@ hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s) {
         break;
         MDHIP_CONV2_RING(X)
 #undef X
-#define X(id, bm, bn, wm, wn)                                                                        \
-    case id:                                                                                       \
-        if (!pw || !conv2_pf_supports(a)) return hipErrorInvalidValue;                             \
-        if ((a.C8 & 7) == 0) hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, 1, 3, 1>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
-        else hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, 0, false, 2, 3, 1>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
-        break;
-        MDHIP_CONV2_RINGPF(X)
-#undef X
 #define X(id, bm, bn, wm, wn, prof)                                                                  \
     case id:                                                                                       \
         hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, prof>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         break;
         MDHIP_CONV2_PROF(X)
 #undef X
-#define X(id, bm, bn, wm, wn, prof, pfw)                                                             \
+#define X(id, bm, bn, wm, wn, prof)                                                                  \
     case id:                                                                                       \
-        if (!pw || (a.C8 & 7) != 0 || !conv2_pf_supports(a)) return hipErrorInvalidValue;          \
-        hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, prof, false, 1, 3, pfw>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
+        if (!pw || (a.C8 & 7) != 0) return hipErrorInvalidValue;                                   \
+        hipLaunchKernelGGL((conv_v2_kernel<bm, bn, wm, wn, prof, false, 1, 3>), grid, dim3((wm) * (wn) * 64), c.lds_bytes, s, p); \
         break;
         MDHIP_CONV2_PROFRING(X)
 #undef X

@@ -731,11 +731,12 @@ struct ConvApi {
     bool (*supports)(int, const ConvArgs&);
     bool (*is_bitwise_family)(int);
     int (*num_v1_cfgs)();
+    bool (*cfg_decodes)(int);
 };
 const ConvApi g_conv_bf16 = {st_bf16::conv_num_cfgs, st_bf16::conv_cfg, st_bf16::conv_launch, st_bf16::conv_init,
-                             st_bf16::conv_supports, st_bf16::conv_cfg_is_bitwise_family, st_bf16::conv_num_v1_cfgs};
+                             st_bf16::conv_supports, st_bf16::conv_cfg_is_bitwise_family, st_bf16::conv_num_v1_cfgs, st_bf16::conv_cfg_decodes};
 const ConvApi g_conv_f16 = {st_f16::conv_num_cfgs, st_f16::conv_cfg, st_f16::conv_launch, st_f16::conv_init,
-                            st_f16::conv_supports, st_f16::conv_cfg_is_bitwise_family, st_f16::conv_num_v1_cfgs};
+                            st_f16::conv_supports, st_f16::conv_cfg_is_bitwise_family, st_f16::conv_num_v1_cfgs, st_f16::conv_cfg_decodes};
 inline const ConvApi& conv_api(const mdhip_ctx* ctx) { return ctx->dtype == MDHIP_DTYPE_FP16 ? g_conv_f16 : g_conv_bf16; }
 // tile configurations (count, names, families) are the same for both storage types
 inline int conv_num_cfgs() { return g_conv_bf16.num_cfgs(); }
@@ -1015,9 +1016,10 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
             if (dec) dec->dec_done = false;
             const bool plain_pass = ctx->cur_tta.keep_from == 0 && ctx->cur_tta.keep_to == 0x7fffffff && ctx->cur_tta.out_off == 0 &&
                                     ctx->cur_tta.scale == 1.0f && ctx->cur_tta.flip_lr == 0;
+            // (pointwise with whole 64-channel slabs: what the decoding instantiations of conv_v2.cpp take)
             auto decodes_in_place = [&](int c) {
                 return dec && ctx->fuse_decode && !ctx->fuse_suspended && ctx->no == 8 && plain_pass && !ctx->calibrating &&
-                       (c < conv_num_v1_cfgs() || strncmp(conv_api(ctx).cfg(c).name, "v2:", 3) == 0);
+                       conv_api(ctx).cfg_decodes(c) && (c < conv_num_v1_cfgs() || (a.C8 & 7) == 0);
             };
             auto set_decode = [&](int c) {
                 a.dec_pred = nullptr;
@@ -1373,9 +1375,7 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
     }
     // the forward that still reads the input tensor (its stem) comes first, whatever stream it runs on
     if (ctx->input_free_valid) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->input_free, 0));
-    bool no_resampling = !ctx->letterbox_general;
-    for (int i = 0; i < n; ++i) no_resampling = no_resampling && g[i].resized_h == g[i].src_h && g[i].resized_w == g[i].src_w;
-    if (!letterbox_geometry_travels_inline(n, out_w, no_resampling)) {
+    if (!letterbox_geometry_travels_inline(g.data(), n, out_w, ctx->letterbox_general)) {
         // geometry goes through a 4-deep pinned ring so that the call never blocks on the stream
         const int slot = ctx->geom_slot;
         ctx->geom_slot = (slot + 1) & 3;
@@ -1386,7 +1386,7 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
         HIP_TRY(ctx, hipEventRecord(ctx->geom_ev[slot], s));
     }
     HIP_TRY(ctx, launch_letterbox_s2d((const LetterboxDev*)(ctx->arena + ctx->geom_off), g.data(), n, out_h, out_w,
-                                      (uint16_t*)(ctx->arena + ctx->input.off), ctx->dtype == MDHIP_DTYPE_FP16, no_resampling, s));
+                                      (uint16_t*)(ctx->arena + ctx->input.off), ctx->dtype == MDHIP_DTYPE_FP16, ctx->letterbox_general, s));
     ctx->last_n = n;
     ctx->last_h = out_h;
     ctx->last_w = out_w;

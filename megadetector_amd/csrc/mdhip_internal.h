@@ -285,13 +285,13 @@ struct ConvCfg {
     hipError_t conv_init(); \
     bool conv_supports(int cfg, const ConvArgs& a); \
     bool conv_cfg_is_bitwise_family(int cfg); \
+    bool conv_cfg_decodes(int cfg); \
+    bool conv2_cfg_decodes(int cfg); \
     int conv_num_v1_cfgs(); \
     int conv2_num_cfgs(); \
     const ConvCfg& conv2_cfg(int i); \
     bool conv2_supports(const ConvArgs& a); \
     bool conv2_cfg_is_ring(int cfg); \
-    bool conv2_cfg_is_pf(int cfg); \
-    bool conv2_pf_supports(const ConvArgs& a); \
     bool conv2_is_pointwise(const ConvArgs& a); \
     hipError_t conv2_launch(int cfg, const ConvArgs& a, hipStream_t s); \
     hipError_t conv2_init(); \
@@ -342,12 +342,14 @@ struct LetterboxDev {     // device copy of mdhip_letterbox + source pointer
     int interp;           // 0: cv2.INTER_LINEAR, 1: cv2.INTER_AREA (shrinking only)
 };
 // u8 HWC -> space-to-depth bf16 [n][out_h/2][out_w/2][16] (12 real channels: (dy,dx,c)), /255
-// (no_resampling: every image of the batch has resized == source size -> the streaming-copy kernel)
-// geom_host: the same geometry in host memory; when letterbox_geometry_travels_inline(...) it is passed in the kernel
-// arguments and geom_dev is not read (the caller skips the upload)
-bool letterbox_geometry_travels_inline(int n, int out_w, bool no_resampling);
+// Three kernels, chosen per batch from the geometry: a streaming copy (no image resampled), a streaming bilinear kernel
+// (cv2.INTER_LINEAR, every real camera image) and the general one (INTER_AREA, very wide sources); force_general = the last
+// one whatever the batch (tests, A/B).  geom_host: the geometry in host memory (source pointers are device pointers); when
+// letterbox_geometry_travels_inline(...) it is passed in the kernel arguments and geom_dev is not read (the caller skips
+// the upload)
+bool letterbox_geometry_travels_inline(const LetterboxDev* geom_host, int n, int out_w, bool force_general);
 hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, const LetterboxDev* geom_host, int n, int out_h, int out_w,
-                                uint16_t* out, int f16, bool no_resampling, hipStream_t s);
+                                uint16_t* out, int f16, bool force_general, hipStream_t s);
 // SPPF: three chained 5x5/s1/p2 max pools of slice 0 written to slices 1..3 of the same buffer
 hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, int k, int f16, hipStream_t s);
 // nearest x2 upsample of a view into a view

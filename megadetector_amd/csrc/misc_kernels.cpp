@@ -23,9 +23,21 @@ namespace mdhip {
 // Bilinear = OpenCV's 8-bit path: 11-bit coefficients, horizontal pass to int, vertical
 // pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double linear_scale(int dst_len, int src_len) { return 1.0 / ((double)dst_len / (double)src_len); }
+__device__ __forceinline__ void linear_coef_s(int d, double scale, int src_len, int& s0, int& s1, int& w0, int& w1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src_len - 1) { f = 0.f; s = src_len - 1; }
+    w1 = __float2int_rn(f * 2048.0f);
+    w0 = __float2int_rn((1.0f - f) * 2048.0f);
+    s0 = s;
+    s1 = min(s + 1, src_len - 1);
+}
 __device__ __forceinline__ void linear_coef(int d, int dst_len, int src_len, int& s0, int& s1,
                                             int& w0, int& w1) {
-    const double scale = 1.0 / ((double)dst_len / (double)src_len);
+    const double scale = linear_scale(dst_len, src_len);
     float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
@@ -250,26 +262,180 @@ letterbox_copy_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w,
     }
 }
 
-static bool lb_copy_kernel_ok(int out_w, bool no_resampling) {
-    return no_resampling && (out_w % 4) == 0 && 512 + (size_t)out_w * 12 <= 65536;
+
+// [r6] The bilinear path (cv2.INTER_LINEAR, what yolov5's letterbox() runs for every real camera image: reference
+// pytorch_detector.py:1104-1109) built the same way: two streaming reads and one streaming write per output row instead of a
+// gather per output byte.  A workgroup owns one space-to-depth row (two output rows) of one image:
+//   phase 0: the u8 -> storage-type table of the copy kernel (the general kernel's expression);
+//   phase 1: the (at most four) source rows the two output rows interpolate between come in as ALIGNED dwords, are
+//            re-aligned with v_alignbyte and land in LDS byte for byte (rows the two output rows share are loaded once);
+//   phase 2: a thread takes two adjacent output columns: the fixed-point column weights once (linear_coef_s: the general
+//            kernel's arithmetic on a hoisted scale), then for either output row the two source pixels of both source
+//            rows as three aligned LDS dwords + two v_alignbyte each, OpenCV's horizontal and vertical passes
+//            ((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2), the table, and twelve bytes into the staged
+//            output row; columns / rows of the border: table[114];
+//   phase 3: the copy kernel's store phase (one 16-byte store per lane on consecutive chunks).
+// Images of the batch that are not resampled go through the same arithmetic with unit weights (exact: x * 2048 >> 4 ...
+// >> 2 returns x).  Same statements as letterbox_s2d_kernel per output value: bit-identical (tests: 6 + 4 shapes).
+constexpr int kLbLinMaxSrcW = 5120;       // 4 source rows x 3 x 5120 bytes + two staged output rows fit the 160 KiB of LDS with room to spare
+__global__ void __launch_bounds__(256)
+letterbox_linear_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w, int src_row_dw,
+                            uint16_t* __restrict__ out, int f16) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lb_lds[];
+    uint16_t* lut = (uint16_t*)lb_lds;                          // 256 entries
+    uint32_t* rows = lb_lds + 128;                              // 2 staged output rows x (out_w * 3 / 2) dwords
+    const int img = blockIdx.y, Y = blockIdx.x, t = threadIdx.x;
+    const int W2 = out_w >> 1, H2 = out_h >> 1;
+    const int row_dw = (out_w * 3) >> 1;
+    uint32_t* srows = rows + 2 * row_dw;                        // 4 source-row slots of src_row_dw dwords
+    const LetterboxDev g = geom.ptr ? geom.ptr[img] : geom.inl[img];
+    lut[t] = f32_to_st((float)t / 255.0f, f16);
+    const int row_bytes = g.src_w * 3;
+    // vertical weights of the two output rows and the source rows they need (slot k of row dy: 2 * dy + k)
+    const double sy = linear_scale(g.resized_h, g.src_h), sx = linear_scale(g.resized_w, g.src_w);
+    int ysrc[4] = {0, 0, 0, 0}, bw[4] = {2048, 0, 2048, 0};
+    bool y_in[2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int y = 2 * Y + dy - g.top;
+        y_in[dy] = (unsigned)y < (unsigned)g.resized_h;
+        if (y_in[dy]) linear_coef_s(y, sy, g.src_h, ysrc[2 * dy], ysrc[2 * dy + 1], bw[2 * dy], bw[2 * dy + 1]);
+    }
+    // slot of every (row, k): an earlier slot that holds the same source row, else its own
+    int slot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        slot[k] = k;
+#pragma unroll
+        for (int j = k - 1; j >= 0; --j)
+            if (ysrc[j] == ysrc[k] && y_in[j >> 1] && y_in[k >> 1]) slot[k] = slot[j];
+    }
+    const int groups = (row_bytes + 3) >> 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!y_in[k >> 1] || slot[k] != k) continue;            // (workgroup-uniform)
+        const uintptr_t a0 = (uintptr_t)(g.src + (size_t)ysrc[k] * row_bytes);
+        const uint32_t* al = (const uint32_t*)(a0 & ~(uintptr_t)3);
+        const uint32_t sh = (uint32_t)(a0 & 3);
+        uint32_t* dst = srows + k * src_row_dw;
+        for (int gi = t; gi < groups; gi += 256) {
+            const uint32_t w0 = al[gi];
+            // (the second dword only where it holds a byte of the row: nothing past the dword of the row's last byte is read)
+            const uint32_t w1 = (sh && 4 * (gi + 1) < (int)sh + row_bytes) ? al[gi + 1] : 0u;
+            dst[gi] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        }
+    }
+    __syncthreads();
+    const uint32_t pad1 = lut[114];
+    // six consecutive bytes (two RGB pixels) at byte offset o of a staged source row: three aligned dwords + two alignbytes
+    auto six = [&](const uint32_t* row, int o, uint32_t& lo, uint32_t& hi) __attribute__((always_inline)) {
+        const uint32_t* q = row + (o >> 2);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        const uint32_t sh = (uint32_t)(o & 3);
+        lo = __builtin_amdgcn_alignbyte(d1, d0, sh);            // bytes o .. o + 3
+        hi = __builtin_amdgcn_alignbyte(d2, d1, sh);            // bytes o + 4 .. o + 7
+    };
+    for (int xp = t; xp < W2; xp += 256) {                      // output columns 2 xp, 2 xp + 1
+        int x0[2], x1[2], a0[2], a1[2];
+        bool x_in[2];
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int x = 2 * xp + dx - g.left;
+            x_in[dx] = (unsigned)x < (unsigned)g.resized_w;
+            x0[dx] = x1[dx] = 0; a0[dx] = 2048; a1[dx] = 0;
+            if (x_in[dx]) linear_coef_s(x, sx, g.src_w, x0[dx], x1[dx], a0[dx], a1[dx]);
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            uint32_t o16[6];
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                uint32_t v[3] = {pad1, pad1, pad1};
+                if (y_in[dy] && x_in[dx]) {
+                    const uint32_t* r0 = srows + slot[2 * dy] * src_row_dw;
+                    const uint32_t* r1 = srows + slot[2 * dy + 1] * src_row_dw;
+                    uint32_t lo0, hi0, lo1, hi1;
+                    six(r0, x0[dx] * 3, lo0, hi0);
+                    six(r1, x0[dx] * 3, lo1, hi1);
+                    // pixel x1 is the next pixel (bytes 3 .. 5) or, clamped at the right edge, pixel x0 again
+                    const bool same = x1[dx] == x0[dx];
+                    const int b0 = bw[2 * dy], b1 = bw[2 * dy + 1];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int p00 = (int)((lo0 >> (8 * c)) & 0xff), p10 = (int)((lo1 >> (8 * c)) & 0xff);
+                        const uint32_t n0 = c == 0 ? (lo0 >> 24) : (hi0 >> (8 * (c - 1))), n1 = c == 0 ? (lo1 >> 24) : (hi1 >> (8 * (c - 1)));
+                        const int p01 = same ? p00 : (int)(n0 & 0xff), p11 = same ? p10 : (int)(n1 & 0xff);
+                        const int t0 = p00 * a0[dx] + p01 * a1[dx];
+                        const int t1 = p10 * a0[dx] + p11 * a1[dx];
+                        const int o = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                        v[c] = lut[min(max(o, 0), 255)];
+                    }
+                }
+                o16[3 * dx] = v[0]; o16[3 * dx + 1] = v[1]; o16[3 * dx + 2] = v[2];
+            }
+            uint32_t* dst = rows + dy * row_dw + 3 * xp;
+            dst[0] = o16[0] | (o16[1] << 16);
+            dst[1] = o16[2] | (o16[3] << 16);
+            dst[2] = o16[4] | (o16[5] << 16);
+        }
+    }
+    __syncthreads();
+    uint4* orow = (uint4*)(out + ((size_t)img * H2 + Y) * (size_t)W2 * 16);
+    const uint32_t* r0 = rows;
+    const uint32_t* r1 = rows + row_dw;
+    for (int q = t; q < 2 * W2; q += 256) {
+        const int X = q >> 1;
+        uint4 v;
+        if (q & 1) v = make_uint4(r1[3 * X + 1], r1[3 * X + 2], 0u, 0u);
+        else v = make_uint4(r0[3 * X], r0[3 * X + 1], r0[3 * X + 2], r1[3 * X]);
+        orow[q] = v;
+    }
 }
-bool letterbox_geometry_travels_inline(int n, int out_w, bool no_resampling) {
-    return lb_copy_kernel_ok(out_w, no_resampling) && n <= kLbInline;
+
+// which kernel a batch takes: 1 = streaming copy (no image is resampled), 2 = streaming bilinear (every resampled image with
+// cv2.INTER_LINEAR, source rows short enough for the LDS), 0 = the general kernel (INTER_AREA, very wide sources, odd widths)
+struct LbPlan { int kind; int src_row_dw; size_t lds; };
+static LbPlan lb_plan(const LetterboxDev* g, int n, int out_w, bool force_general) {
+    LbPlan p{0, 0, 0};
+    if (force_general || (out_w % 4) != 0) return p;
+    bool no_resampling = true, linear = true;
+    int max_src_w = 0;
+    for (int i = 0; i < n; ++i) {
+        const bool rs = g[i].resized_h != g[i].src_h || g[i].resized_w != g[i].src_w;
+        no_resampling = no_resampling && !rs;
+        linear = linear && (!rs || g[i].interp == 0);
+        max_src_w = std::max(max_src_w, g[i].src_w);
+    }
+    if (no_resampling) {
+        p.lds = 512 + (size_t)out_w * 12;
+        if (p.lds <= 65536) p.kind = 1;
+        return p;
+    }
+    if (linear && max_src_w <= kLbLinMaxSrcW) {
+        p.src_row_dw = (max_src_w * 3 + 3) / 4 + 4;            // + the dwords six() reads behind the last pixel
+        p.lds = 512 + (size_t)out_w * 12 + (size_t)p.src_row_dw * 16;
+        if (p.lds <= 65536) p.kind = 2;
+    }
+    return p;
+}
+bool letterbox_geometry_travels_inline(const LetterboxDev* geom_host, int n, int out_w, bool force_general) {
+    return lb_plan(geom_host, n, out_w, force_general).kind != 0 && n <= kLbInline;
 }
 
 hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, const LetterboxDev* geom_host, int n, int out_h, int out_w,
-                                uint16_t* out, int f16, bool no_resampling, hipStream_t s) {
+                                uint16_t* out, int f16, bool force_general, hipStream_t s) {
     const int W2 = out_w / 2, H2 = out_h / 2;
-    const size_t lds = 512 + (size_t)out_w * 12;
-    if (lb_copy_kernel_ok(out_w, no_resampling)) {
+    const LbPlan plan = lb_plan(geom_host, n, out_w, force_general);
+    if (plan.kind != 0) {
         LetterboxGeom geom;
         geom.ptr = geom_dev;
-        if (letterbox_geometry_travels_inline(n, out_w, no_resampling)) {
+        if (n <= kLbInline) {
             geom.ptr = nullptr;
             for (int i = 0; i < n; ++i) geom.inl[i] = geom_host[i];
             for (int i = n; i < kLbInline; ++i) geom.inl[i] = LetterboxDev{nullptr, 0, 0, 0, 0, 0, 0, 0};
         }
-        hipLaunchKernelGGL(letterbox_copy_s2d_kernel, dim3(H2, n), dim3(256), lds, s, geom, out_h, out_w, out, f16);
+        if (plan.kind == 1) hipLaunchKernelGGL(letterbox_copy_s2d_kernel, dim3(H2, n), dim3(256), plan.lds, s, geom, out_h, out_w, out, f16);
+        else hipLaunchKernelGGL(letterbox_linear_s2d_kernel, dim3(H2, n), dim3(256), plan.lds, s, geom, out_h, out_w, plan.src_row_dw, out, f16);
         return hipGetLastError();
     }
     dim3 grid((W2 + 255) / 256, H2, n);
@@ -328,9 +494,11 @@ sppf_pool_kernel(uint16_t* __restrict__ buf, int ld, int c8, int n, int h, int w
 // The three chained pools in ONE launch when an image's map fits in LDS (the 20x20 .. 40x40 maps SPPF sees): a workgroup
 // takes CH 8-channel chunks of one image, loads them once, and runs row-max then column-max (5 + 5 instead of 25 reads
 // per output) three times between two LDS buffers, writing each stage to its slice.  max is exact: same bits as the
-// chained launches.  0.186 -> 0.10 ms per step at batch 32.
+// chained launches.  0.186 -> 0.10 ms per step at batch 32.  [r6] 1024 threads per workgroup when the map has at least that many
+// (pixel, chunk) items: the kernel is latency-bound (six barrier-separated passes of a few dependent LDS reads per thread), so what
+// helps is more waves per pass, not fewer bytes.
 template <int CH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 sppf_pool_lds_kernel(uint16_t* __restrict__ buf, int ld, int c8, int h, int w, int r1, int f16) {
     extern __shared__ __attribute__((aligned(16))) uint4 sp[];
     const int hw = h * w, items = hw * CH;
@@ -341,13 +509,13 @@ sppf_pool_lds_kernel(uint16_t* __restrict__ buf, int ld, int c8, int h, int w, i
     const int c = c8 * 8;
     uint16_t* img = buf + (size_t)b * hw * ld;
     const uint32_t ninf2 = f16 ? 0xfc00fc00u : 0xff80ff80u;
-    for (int t = threadIdx.x; t < items; t += 256) {
+    for (int t = threadIdx.x; t < items; t += (int)blockDim.x) {
         const int pix = t / CH, ch = g * CH + (t - pix * CH);
         A[t] = ch < c8 ? *(const uint4*)(img + (size_t)pix * ld + ch * 8) : make_uint4(ninf2, ninf2, ninf2, ninf2);
     }
     __syncthreads();
     for (int stage = 0; stage < 3; ++stage) {
-        for (int t = threadIdx.x; t < items; t += 256) {
+        for (int t = threadIdx.x; t < items; t += (int)blockDim.x) {
             const int pix = t / CH, k = t - pix * CH, y = pix / w, x = pix - y * w;
             uint4 m = make_uint4(ninf2, ninf2, ninf2, ninf2);
             for (int dx = -r1; dx <= r1; ++dx)
@@ -355,7 +523,7 @@ sppf_pool_lds_kernel(uint16_t* __restrict__ buf, int ld, int c8, int h, int w, i
             T[t] = m;
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < items; t += 256) {
+        for (int t = threadIdx.x; t < items; t += (int)blockDim.x) {
             const int pix = t / CH, k = t - pix * CH, y = pix / w, ch = g * CH + k;
             uint4 m = make_uint4(ninf2, ninf2, ninf2, ninf2);
             for (int dy = -r1; dy <= r1; ++dy)
@@ -371,7 +539,8 @@ hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, i
     const long long total = (long long)n * h * w * (c / 8);
     const size_t per_chunk = (size_t)h * w * 16 * 2;                // two LDS buffers of one 8-channel chunk of the map
     if (per_chunk * 4 <= 65536) {
-        hipLaunchKernelGGL(sppf_pool_lds_kernel<4>, dim3((unsigned)(n * ((c / 8 + 3) / 4))), dim3(256), per_chunk * 4, s,
+        const int threads = h * w * 4 >= 1024 ? 1024 : 256;
+        hipLaunchKernelGGL(sppf_pool_lds_kernel<4>, dim3((unsigned)(n * ((c / 8 + 3) / 4))), dim3(threads), per_chunk * 4, s,
                            buf, ld, c / 8, h, w, k / 2, f16);
         return hipGetLastError();
     }

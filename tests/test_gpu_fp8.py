@@ -212,7 +212,8 @@ def test_fp8_full_size_image_with_the_batch_64_tiles_and_scales_from_another_ima
         # 640x640 (two images, scales from the evaluated batch): measured 4.5e-2 / 3.2e-2 under bars of 8e-2 / 5e-2.  Here: 4x the
         # values per layer (the max is an extreme-value statistic: x 1.7 for bf16, tests/test_gpu_headline.py) and scales from
         # ANOTHER image, 2x head-room over ITS range: measured 9.0e-2 (layer 15) / 4.7e-2 (layers 15 / 32)
-        bad = [t for t in rows if t[1] > 1.3e-1 or t[2] > 6.5e-2]
+        # [r6] bars at 1.3x the measured values (they are deterministic for a given tile table): a broken kernel is off by far more
+        bad = [t for t in rows if t[1] > 1.2e-1 or t[2] > 6.0e-2]
         assert len(rows) >= 30 and not bad, bad
         assert rows[2][0] == 2 and rows[2][2] < FP8_FIRST_BLOCK_MEAN_TOL, rows[2]
         d8 = float(np.abs(pred[..., 4:] - pred8[..., 4:].numpy()).max())
@@ -221,7 +222,8 @@ def test_fp8_full_size_image_with_the_batch_64_tiles_and_scales_from_another_ima
         print('fp8 x6 1280x1280: |d conf| vs fp8 oracle {:.4f}, vs fp32 oracle {:.4f}'.format(d8, d32))
         # (640x640 with scales from the evaluated batch: 0.114 / 0.127 under FP8_CONF_TOL_FP32_ORACLE = 0.15; here the scales come
         # from ANOTHER image and 102 000 anchors are looked at on the seeded weights' Detect gain of 22: measured 0.19)
-        assert d8 < 0.25 and d32 < 0.25
+        # [r6] measured 0.1888 against the fp8-emulating oracle, 0.2181 against the fp32 one
+        assert d8 < 0.22 and d32 < 0.25
         # the same image next to the other one: the same bits
         ctx.preprocess([other, im], _identity_geoms([other, im]), HH, WW)
         ctx.forward(2, HH, WW)

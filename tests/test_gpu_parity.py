@@ -125,6 +125,49 @@ def test_preprocess_streaming_copy_kernel_bit_exact(n6, shape, monkeypatch):
         ctx.set_option('letterbox_general', 0)
 
 
+@pytest.mark.parametrize('case', ['down_4x3', 'up', 'mixed_sources', 'tiny', 'one_axis'])
+def test_preprocess_streaming_bilinear_kernel_bit_exact(n6, case):
+    """[r6] batches whose images are resampled with cv2.INTER_LINEAR (every real camera image: reference
+    pytorch_detector.py:1104-1109) take the streaming bilinear letterbox kernel (source rows staged in LDS as aligned
+    dwords, column weights once per column pair, OpenCV's two fixed-point passes, the u8 -> storage-type table, 16-byte
+    stores): bit-exact against the oracle's letterbox AND against the general kernel (mdhip_set_option
+    "letterbox_general"), for shrinking and enlarging, sources of different sizes in one batch (one of them not resampled at
+    all), images of a few pixels, a resize along one axis only, and device pointers at odd addresses."""
+    from megadetector_amd.postprocess import letterbox_geometry
+    W, ctx = n6
+    shapes = {'down_4x3': [(384, 512)] * 2, 'up': [(60, 100), (120, 200)], 'mixed_sources': [(192, 256), (600, 800), (96, 128)],
+              'tiny': [(3, 5), (6, 10)], 'one_axis': [(255, 100)] * 2}[case]
+    imgs = [PU.structured_images(1, hh, ww, seed=hh + 3 * ww)[0] for hh, ww in shapes]
+    geoms, out = [], None
+    for (hh, ww) in shapes:
+        g = letterbox_geometry((hh, ww), new_shape=256, stride=64)
+        geoms.append((hh, ww, g['new_unpad'][1], g['new_unpad'][0], g['top'], g['left']))
+        assert out in (None, g['out_hw']), 'the images of one batch letterbox to one shape'
+        out = g['out_hw']
+    h, w = out
+    n = len(imgs)
+    want = np.concatenate([PU.bf16_round_np(PU.oracle_input([im], 256, 64)[0].numpy()) for im in imgs], 0)
+    assert want.shape[2:] == (h, w)
+    ctx.preprocess(imgs, geoms, h, w)
+    np.testing.assert_array_equal(ctx.read_input(n, h, w), want)
+    # device-resident sources at odd addresses
+    bufs, ptrs = [], []
+    for k, im in enumerate(imgs):
+        b = torch.zeros(im.size + 8, dtype=torch.uint8, device='cuda')
+        b[k + 1:k + 1 + im.size] = torch.from_numpy(im.reshape(-1)).cuda()
+        bufs.append(b)
+        ptrs.append(int(b.data_ptr()) + k + 1)
+    torch.cuda.synchronize()
+    ctx.preprocess(ptrs, geoms, h, w)
+    np.testing.assert_array_equal(ctx.read_input(n, h, w), want)
+    ctx.set_option('letterbox_general', 1)
+    try:
+        ctx.preprocess(ptrs, geoms, h, w)
+        np.testing.assert_array_equal(ctx.read_input(n, h, w), want)
+    finally:
+        ctx.set_option('letterbox_general', 0)
+
+
 # ---------------------------------------------------------------------------------------
 # conv stack: layer by layer against the bf16-emulating oracle
 # ---------------------------------------------------------------------------------------
