@@ -277,19 +277,20 @@ letterbox_copy_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w,
 //   phase 3: the copy kernel's store phase (one 16-byte store per lane on consecutive chunks).
 // Images of the batch that are not resampled go through the same arithmetic with unit weights (exact: x * 2048 >> 4 ...
 // >> 2 returns x).  Same statements as letterbox_s2d_kernel per output value: bit-identical (tests: 6 + 4 shapes).
-constexpr int kLbLinMaxSrcW = 5120;       // 4 source rows x 3 x 5120 bytes + two staged output rows fit the 160 KiB of LDS with room to spare
-__global__ void __launch_bounds__(256)
+constexpr int kLbLinMaxSrcW = 5120;
+constexpr int kLbLinThreads = 320;        // 640 column pairs of a 1280-wide row = two per thread
+__global__ void __launch_bounds__(kLbLinThreads)
 letterbox_linear_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w, int src_row_dw,
                             uint16_t* __restrict__ out, int f16) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lb_lds[];
     uint16_t* lut = (uint16_t*)lb_lds;                          // 256 entries
     uint32_t* rows = lb_lds + 128;                              // 2 staged output rows x (out_w * 3 / 2) dwords
-    const int img = blockIdx.y, Y = blockIdx.x, t = threadIdx.x;
+    const int img = blockIdx.y, Y = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
     const int W2 = out_w >> 1, H2 = out_h >> 1;
     const int row_dw = (out_w * 3) >> 1;
     uint32_t* srows = rows + 2 * row_dw;                        // 4 source-row slots of src_row_dw dwords
     const LetterboxDev g = geom.ptr ? geom.ptr[img] : geom.inl[img];
-    lut[t] = f32_to_st((float)t / 255.0f, f16);
+    if (t < 256) lut[t] = f32_to_st((float)t / 255.0f, f16);
     const int row_bytes = g.src_w * 3;
     // vertical weights of the two output rows and the source rows they need (slot k of row dy: 2 * dy + k)
     const double sy = linear_scale(g.resized_h, g.src_h), sx = linear_scale(g.resized_w, g.src_w);
@@ -301,73 +302,105 @@ letterbox_linear_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w, int 
         y_in[dy] = (unsigned)y < (unsigned)g.resized_h;
         if (y_in[dy]) linear_coef_s(y, sy, g.src_h, ysrc[2 * dy], ysrc[2 * dy + 1], bw[2 * dy], bw[2 * dy + 1]);
     }
-    // slot of every (row, k): an earlier slot that holds the same source row, else its own
+    // slot of every (row, k): an earlier slot that holds the same source row, else its own; `need` = the slots to load
     int slot[4];
+    bool need[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         slot[k] = k;
 #pragma unroll
         for (int j = k - 1; j >= 0; --j)
             if (ysrc[j] == ysrc[k] && y_in[j >> 1] && y_in[k >> 1]) slot[k] = slot[j];
+        need[k] = y_in[k >> 1] && slot[k] == k;
     }
+    // phase 1: the needed source rows, five dwords per thread and row at a time: every load of a batch (up to 4 rows x 5 x 2)
+    // is issued before the first is used (the rows are read once, at memory latency -- what bounds this phase is the number
+    // of loads in flight, not their number)
     const int groups = (row_bytes + 3) >> 2;
+    {
+        const uint32_t* al[4];
+        uint32_t sh[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (!y_in[k >> 1] || slot[k] != k) continue;            // (workgroup-uniform)
-        const uintptr_t a0 = (uintptr_t)(g.src + (size_t)ysrc[k] * row_bytes);
-        const uint32_t* al = (const uint32_t*)(a0 & ~(uintptr_t)3);
-        const uint32_t sh = (uint32_t)(a0 & 3);
-        uint32_t* dst = srows + k * src_row_dw;
-        for (int gi = t; gi < groups; gi += 256) {
-            const uint32_t w0 = al[gi];
-            // (the second dword only where it holds a byte of the row: nothing past the dword of the row's last byte is read)
-            const uint32_t w1 = (sh && 4 * (gi + 1) < (int)sh + row_bytes) ? al[gi + 1] : 0u;
-            dst[gi] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        for (int k = 0; k < 4; ++k) {
+            const uintptr_t a0 = (uintptr_t)(g.src + (size_t)ysrc[k] * row_bytes);
+            al[k] = (const uint32_t*)(a0 & ~(uintptr_t)3);
+            sh[k] = (uint32_t)(a0 & 3);
+        }
+        constexpr int NB = 5;                                   // (x 4 rows x 2 dwords: 40 registers; 128 registers = three workgroups per CU)
+        for (int base = 0; base < groups; base += NB * nt) {    // (one trip for sources up to 2 100 pixels wide)
+            uint32_t w0[4][NB], w1[4][NB];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!need[k]) continue;                         // (workgroup-uniform)
+                // the last dword that holds a byte of the row: no lane reads past it (lanes behind the row re-read it)
+                const int last = ((int)sh[k] + row_bytes - 1) >> 2;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int gi = min(base + u * nt + t, groups - 1);
+                    w0[k][u] = al[k][gi];
+                    w1[k][u] = sh[k] ? al[k][min(gi + 1, last)] : 0u;      // (uniform condition)
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!need[k]) continue;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int gi = base + u * nt + t;
+                    if (gi < groups) srows[k * src_row_dw + gi] = __builtin_amdgcn_alignbyte(w1[k][u], w0[k][u], sh[k]);
+                }
+            }
         }
     }
     __syncthreads();
     const uint32_t pad1 = lut[114];
-    // six consecutive bytes (two RGB pixels) at byte offset o of a staged source row: three aligned dwords + two alignbytes
-    auto six = [&](const uint32_t* row, int o, uint32_t& lo, uint32_t& hi) __attribute__((always_inline)) {
+    // phase 2.  Two RGB pixels = six consecutive bytes at byte offset o of a staged source row: three aligned dwords, two
+    // v_alignbyte; channel c of both pixels as (p0 | p1 << 16) with one v_perm_b32, the horizontal pass p0 * a0 + p1 * a1
+    // with one v_dot2_u32_u16 -- integer arithmetic, the same values as the general kernel's products and sum.  (At the
+    // right edge x1 == x0 and a1 == 0: the bytes behind the row's last pixel are multiplied by zero.)
+    auto hpass = [&](const uint32_t* row, int o, uint32_t aw, uint32_t (&tc)[3]) __attribute__((always_inline)) {
         const uint32_t* q = row + (o >> 2);
         const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
         const uint32_t sh = (uint32_t)(o & 3);
-        lo = __builtin_amdgcn_alignbyte(d1, d0, sh);            // bytes o .. o + 3
-        hi = __builtin_amdgcn_alignbyte(d2, d1, sh);            // bytes o + 4 .. o + 7
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);            // bytes o .. o + 3
+        const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);            // bytes o + 4 .. o + 7
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const u16x2 a2 = *(const u16x2*)&aw;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t pp = __builtin_amdgcn_perm(hi, lo, (uint32_t)(c | (0x0c << 8) | ((c + 3) << 16) | (0x0cu << 24)));
+            tc[c] = __builtin_amdgcn_udot2(*(const u16x2*)&pp, a2, 0u, false);
+        }
     };
-    for (int xp = t; xp < W2; xp += 256) {                      // output columns 2 xp, 2 xp + 1
-        int x0[2], x1[2], a0[2], a1[2];
+    for (int xp = t; xp < W2; xp += nt) {                       // output columns 2 xp, 2 xp + 1
+        int x0[2];
+        uint32_t aw[2];
         bool x_in[2];
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
             const int x = 2 * xp + dx - g.left;
             x_in[dx] = (unsigned)x < (unsigned)g.resized_w;
-            x0[dx] = x1[dx] = 0; a0[dx] = 2048; a1[dx] = 0;
-            if (x_in[dx]) linear_coef_s(x, sx, g.src_w, x0[dx], x1[dx], a0[dx], a1[dx]);
+            int x1 = 0, a0 = 2048, a1 = 0;
+            x0[dx] = 0;
+            if (x_in[dx]) linear_coef_s(x, sx, g.src_w, x0[dx], x1, a0, a1);
+            aw[dx] = (uint32_t)a0 | ((uint32_t)a1 << 16);
         }
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             uint32_t o16[6];
+            const uint32_t* r0 = srows + slot[2 * dy] * src_row_dw;
+            const uint32_t* r1 = srows + slot[2 * dy + 1] * src_row_dw;
+            const int b0 = bw[2 * dy], b1 = bw[2 * dy + 1];
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 uint32_t v[3] = {pad1, pad1, pad1};
                 if (y_in[dy] && x_in[dx]) {
-                    const uint32_t* r0 = srows + slot[2 * dy] * src_row_dw;
-                    const uint32_t* r1 = srows + slot[2 * dy + 1] * src_row_dw;
-                    uint32_t lo0, hi0, lo1, hi1;
-                    six(r0, x0[dx] * 3, lo0, hi0);
-                    six(r1, x0[dx] * 3, lo1, hi1);
-                    // pixel x1 is the next pixel (bytes 3 .. 5) or, clamped at the right edge, pixel x0 again
-                    const bool same = x1[dx] == x0[dx];
-                    const int b0 = bw[2 * dy], b1 = bw[2 * dy + 1];
+                    uint32_t t0[3], t1[3];
+                    hpass(r0, x0[dx] * 3, aw[dx], t0);
+                    hpass(r1, x0[dx] * 3, aw[dx], t1);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const int p00 = (int)((lo0 >> (8 * c)) & 0xff), p10 = (int)((lo1 >> (8 * c)) & 0xff);
-                        const uint32_t n0 = c == 0 ? (lo0 >> 24) : (hi0 >> (8 * (c - 1))), n1 = c == 0 ? (lo1 >> 24) : (hi1 >> (8 * (c - 1)));
-                        const int p01 = same ? p00 : (int)(n0 & 0xff), p11 = same ? p10 : (int)(n1 & 0xff);
-                        const int t0 = p00 * a0[dx] + p01 * a1[dx];
-                        const int t1 = p10 * a0[dx] + p11 * a1[dx];
-                        const int o = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                        const int o = (((b0 * (int)(t0[c] >> 4)) >> 16) + ((b1 * (int)(t1[c] >> 4)) >> 16) + 2) >> 2;
                         v[c] = lut[min(max(o, 0), 255)];
                     }
                 }
@@ -383,7 +416,7 @@ letterbox_linear_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w, int 
     uint4* orow = (uint4*)(out + ((size_t)img * H2 + Y) * (size_t)W2 * 16);
     const uint32_t* r0 = rows;
     const uint32_t* r1 = rows + row_dw;
-    for (int q = t; q < 2 * W2; q += 256) {
+    for (int q = t; q < 2 * W2; q += nt) {
         const int X = q >> 1;
         uint4 v;
         if (q & 1) v = make_uint4(r1[3 * X + 1], r1[3 * X + 2], 0u, 0u);
@@ -435,7 +468,8 @@ hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, const LetterboxDev
             for (int i = n; i < kLbInline; ++i) geom.inl[i] = LetterboxDev{nullptr, 0, 0, 0, 0, 0, 0, 0};
         }
         if (plan.kind == 1) hipLaunchKernelGGL(letterbox_copy_s2d_kernel, dim3(H2, n), dim3(256), plan.lds, s, geom, out_h, out_w, out, f16);
-        else hipLaunchKernelGGL(letterbox_linear_s2d_kernel, dim3(H2, n), dim3(256), plan.lds, s, geom, out_h, out_w, plan.src_row_dw, out, f16);
+        else hipLaunchKernelGGL(letterbox_linear_s2d_kernel, dim3(H2, n), dim3((W2 % kLbLinThreads) == 0 ? kLbLinThreads : 256), plan.lds, s,
+                                geom, out_h, out_w, plan.src_row_dw, out, f16);
         return hipGetLastError();
     }
     dim3 grid((W2 + 255) / 256, H2, n);

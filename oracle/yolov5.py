@@ -15,7 +15,7 @@ torch.nn.functional primitives -- the same CPU kernels the reference's CPU path 
 PARITY UNPINNED for the conv stack: the reference tree holds no weights, no expected
 logits and no expected detections for this path (they live in md-test-package.zip on
 lila.science, reference md_tests.py:82).  What *is* pinned in-tree and checked in
-tests/test_oracle_model.py: the topology reproduces the upstream FLOP/parameter counts
+tests/test_oracle_golden.py::test_topology_reproduces_published_flops_and_params: the topology reproduces the upstream FLOP/parameter counts
 the reference cites (docs/release-notes/mdv1000-release.md:279: YOLOv5x6, 209.8 GFLOPs,
 140.7 M params @640, nc=80).
 

@@ -29,3 +29,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _remove_checkpoint_fixtures(tmp_path_factory):
+    """the checkpoint files the tests write (tests/fake_yolov5.save_checkpoint: up to 280 MB each at the x6 widths) go when the
+    session ends -- pytest keeps the temporary directories of the last three sessions, and these would stay with them"""
+    yield
+    try:
+        for p in tmp_path_factory.getbasetemp().rglob('*.pt'):
+            try:
+                p.unlink()
+            except OSError:
+                pass
+    except Exception:
+        pass

@@ -10,7 +10,6 @@ the fp32 evaluation (= what the reference computes) is REPORTED and bounded by t
 """
 
 import os
-import tempfile
 
 import numpy as np
 import pytest
@@ -232,7 +231,7 @@ def test_fp8_full_size_image_with_the_batch_64_tiles_and_scales_from_another_ima
         ctx.close()
 
 
-def test_fp8_through_the_detector_seam():
+def test_fp8_through_the_detector_seam(tmp_path):
     """detector_options={'dtype': 'fp8'}: the first batch calibrates; NMS / rescale / formatting exact on the HIP
     predictions; 'fp8_scales' restores a saved calibration"""
     from megadetector_amd import weights_io, yolo_yaml
@@ -241,7 +240,7 @@ def test_fp8_through_the_detector_seam():
     # ADVICE r2 / VERDICT r2 item 4: no silent calibration on whatever batch comes first
     with pytest.raises(ValueError, match='fp8_scales'):
         HIPDetector(W, {'batch_size': 2, 'max_image_size': 384, 'dtype': 'fp8'})
-    scales_file = os.path.join(tempfile.mkdtemp(), 'scales.json')
+    scales_file = str(tmp_path / 'scales.json')
     det = HIPDetector(W, {'batch_size': 2, 'max_image_size': 384, 'dtype': 'fp8',
                           'fp8_calibrate_on_first_batch': True, 'fp8_scales_file': scales_file})
     det.default_image_size = 384
