@@ -126,10 +126,16 @@ conv_v5_kernel(const ConvArgs p) {
     const int ms = slot / p.tiles_n;
     const int xcd_first = xcd * p.tiles_per_xcd;
     const int xcd_tiles = min(p.tiles_per_xcd, p.tiles_m - xcd_first);
-    const int my_tiles = (xcd_tiles > ms) ? (xcd_tiles - ms + p.m_streams - 1) / p.m_streams : 0;
+    // (developer switch, p.dev_param == 55: a stream takes a CONTIGUOUS chunk of its XCD's tiles instead of every m_streams-th one --
+    // the halo rows two vertically adjacent tiles share are then re-read by the same CU one tile later, not by its neighbour at the
+    // same time; round 6, read amplification)
+    const bool chunked = p.dev_param == 55;
+    const int per_stream = (xcd_tiles + p.m_streams - 1) / p.m_streams;
+    const int my_tiles = chunked ? max(0, min(per_stream, xcd_tiles - ms * per_stream))
+                                 : ((xcd_tiles > ms) ? (xcd_tiles - ms + p.m_streams - 1) / p.m_streams : 0);
     if (my_tiles <= 0) return;
-    const int first_tile = xcd_first + ms;
-    const int tile_step = p.m_streams;
+    const int first_tile = chunked ? xcd_first + ms * per_stream : xcd_first + ms;
+    const int tile_step = chunked ? 1 : p.m_streams;
     const int last_tile = first_tile + (my_tiles - 1) * tile_step;
     const int n0 = tile_n * BN;
     const int G = p.groups;                       // 64-channel groups (the last one may be half full)

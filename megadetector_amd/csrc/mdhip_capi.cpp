@@ -1355,7 +1355,8 @@ int mdhip_preprocess(mdhip_ctx* ctx, const uint8_t* const* images, const mdhip_l
         if (q.interp != 0 && q.interp != 1) return fail(ctx, MDHIP_EINVAL, "image %d: interp %d (0 = linear, 1 = area)", i, q.interp);
         if (q.interp == 1 && (q.resized_h > q.src_h || q.resized_w > q.src_w))
             return fail(ctx, MDHIP_EINVAL, "image %d: INTER_AREA is implemented for shrinking only", i);
-        g[i] = LetterboxDev{images[i], q.src_h, q.src_w, q.resized_h, q.resized_w, q.top, q.left, q.interp};
+        g[i] = LetterboxDev{images[i], q.src_h, q.src_w, q.resized_h, q.resized_w, q.top, q.left, q.interp,
+                            1.0 / ((double)q.resized_w / (double)q.src_w), 1.0 / ((double)q.resized_h / (double)q.src_h)};
     }
     if (host_bytes > ctx->stage_bytes) {
         HIP_TRY(ctx, hipStreamSynchronize(s));

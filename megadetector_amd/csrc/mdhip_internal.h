@@ -340,6 +340,9 @@ struct LetterboxDev {     // device copy of mdhip_letterbox + source pointer
     const uint8_t* src;
     int src_h, src_w, resized_h, resized_w, top, left;
     int interp;           // 0: cv2.INTER_LINEAR, 1: cv2.INTER_AREA (shrinking only)
+    // cv2's bilinear scales  1.0 / ((double)resized / (double)src)  per axis, computed on the host with that very expression (IEEE
+    // double on both sides: the bits the kernels' own linear_scale() produces); read by letterbox_linear_s2d_kernel
+    double sx, sy;
 };
 // u8 HWC -> space-to-depth bf16 [n][out_h/2][out_w/2][16] (12 real channels: (dy,dx,c)), /255
 // Three kernels, chosen per batch from the geometry: a streaming copy (no image resampled), a streaming bilinear kernel

@@ -264,191 +264,175 @@ letterbox_copy_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w,
 
 
 // [r6] The bilinear path (cv2.INTER_LINEAR, what yolov5's letterbox() runs for every real camera image: reference
-// pytorch_detector.py:1104-1109) built the same way: two streaming reads and one streaming write per output row instead of a
-// gather per output byte.  A workgroup owns one space-to-depth row (two output rows) of one image:
-//   phase 0: the u8 -> storage-type table of the copy kernel (the general kernel's expression);
-//   phase 1: the (at most four) source rows the two output rows interpolate between come in as ALIGNED dwords, are
-//            re-aligned with v_alignbyte and land in LDS byte for byte (rows the two output rows share are loaded once);
-//   phase 2: a thread takes two adjacent output columns: the fixed-point column weights once (linear_coef_s: the general
-//            kernel's arithmetic on a hoisted scale), then for either output row the two source pixels of both source
-//            rows as three aligned LDS dwords + two v_alignbyte each, OpenCV's horizontal and vertical passes
-//            ((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2), the table, and twelve bytes into the staged
-//            output row; columns / rows of the border: table[114];
-//   phase 3: the copy kernel's store phase (one 16-byte store per lane on consecutive chunks).
-// Images of the batch that are not resampled go through the same arithmetic with unit weights (exact: x * 2048 >> 4 ...
-// >> 2 returns x).  Same statements as letterbox_s2d_kernel per output value: bit-identical (tests: 6 + 4 shapes).
-constexpr int kLbLinMaxSrcW = 5120;
-constexpr int kLbLinThreads = 320;        // 640 column pairs of a 1280-wide row = two per thread
-__global__ void __launch_bounds__(kLbLinThreads)
-letterbox_linear_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w, int src_row_dw,
-                            uint16_t* __restrict__ out, int f16) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lb_lds[];
-    uint16_t* lut = (uint16_t*)lb_lds;                          // 256 entries
-    uint32_t* rows = lb_lds + 128;                              // 2 staged output rows x (out_w * 3 / 2) dwords
-    const int img = blockIdx.y, Y = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+// pytorch_detector.py:1104-1109) with the general kernel's work per output value cut to what the arithmetic needs.  The general
+// kernel spends a thread's time on 6 double-precision divisions (the scale of linear_coef, per call), 12 IEEE divisions by 255,
+// and 48 byte loads (each a full 64-lane gather instruction).  Here, one thread per space-to-depth pixel as there:
+//   * the two scales come with the geometry (computed on the host with the same IEEE double expression: same bits);
+//   * the u8 -> storage-type conversion is the copy kernel's 256-entry table in LDS (the general kernel's expression);
+//   * two RGB pixels of a source row = six consecutive bytes: ONE 12-byte load from the aligned address + two v_alignbyte; channel
+//     c of both pixels as (p0 | p1 << 16) with one v_perm_b32, OpenCV's horizontal pass p0 * a0 + p1 * a1 with one
+//     v_dot2_u32_u16 -- 8 memory instructions per thread instead of 48, integer arithmetic with the general kernel's values;
+//   * the thread's 32 output bytes go through a wave-private 2 KiB of LDS so that each of its two stores covers 1 KiB of contiguous
+//     output (16 bytes per lane on consecutive chunks) instead of every other 16 bytes of 2 KiB.
+// (Sharing the horizontal pass of a source row between the thread's two output rows was tried: the selects it needs cost more
+// than the passes it saves.)
+// First built as a staged kernel (source rows in LDS as aligned dwords, output rows staged for 16-byte stores, two barriers): bit-exact
+// and 10 - 50 % SLOWER than the general kernel on every shape (profiles/r6_letterbox.txt) -- at 15 waves per CU its three
+// barrier-separated phases leave the dependent LDS chains (window -> table) uncovered.  This form has no phase structure.
+// At the right edge (x0 == src_w - 1, where a1 == 0) the window starts one pixel earlier and the weights swap places, so that
+// no window reaches past its row; a window whose 12-byte load would reach past the dword of the image's last byte (the last
+// pixels of the last row) is read byte by byte.
+constexpr int kLbRows = 2;
+__global__ void __launch_bounds__(256)
+letterbox_linear_s2d_kernel(const LetterboxGeom geom, int out_h, int out_w, uint16_t* __restrict__ out, int f16) {
+    __shared__ uint16_t lut[256];
+    __shared__ uint4 stage[4 * 128];                            // 2 KiB per wave (the store transpose below)
+    const int img = blockIdx.z, t = threadIdx.x;
+    const int X = blockIdx.x * 256 + t;                         // s2d column
+    const int Y = blockIdx.y;                                   // s2d rows Y * kLbRows ..
     const int W2 = out_w >> 1, H2 = out_h >> 1;
-    const int row_dw = (out_w * 3) >> 1;
-    uint32_t* srows = rows + 2 * row_dw;                        // 4 source-row slots of src_row_dw dwords
     const LetterboxDev g = geom.ptr ? geom.ptr[img] : geom.inl[img];
-    if (t < 256) lut[t] = f32_to_st((float)t / 255.0f, f16);
-    const int row_bytes = g.src_w * 3;
-    // vertical weights of the two output rows and the source rows they need (slot k of row dy: 2 * dy + k)
-    const double sy = linear_scale(g.resized_h, g.src_h), sx = linear_scale(g.resized_w, g.src_w);
-    int ysrc[4] = {0, 0, 0, 0}, bw[4] = {2048, 0, 2048, 0};
-    bool y_in[2];
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-        const int y = 2 * Y + dy - g.top;
-        y_in[dy] = (unsigned)y < (unsigned)g.resized_h;
-        if (y_in[dy]) linear_coef_s(y, sy, g.src_h, ysrc[2 * dy], ysrc[2 * dy + 1], bw[2 * dy], bw[2 * dy + 1]);
-    }
-    // slot of every (row, k): an earlier slot that holds the same source row, else its own; `need` = the slots to load
-    int slot[4];
-    bool need[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        slot[k] = k;
-#pragma unroll
-        for (int j = k - 1; j >= 0; --j)
-            if (ysrc[j] == ysrc[k] && y_in[j >> 1] && y_in[k >> 1]) slot[k] = slot[j];
-        need[k] = y_in[k >> 1] && slot[k] == k;
-    }
-    // phase 1: the needed source rows, five dwords per thread and row at a time: every load of a batch (up to 4 rows x 5 x 2)
-    // is issued before the first is used (the rows are read once, at memory latency -- what bounds this phase is the number
-    // of loads in flight, not their number)
-    const int groups = (row_bytes + 3) >> 2;
-    {
-        const uint32_t* al[4];
-        uint32_t sh[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uintptr_t a0 = (uintptr_t)(g.src + (size_t)ysrc[k] * row_bytes);
-            al[k] = (const uint32_t*)(a0 & ~(uintptr_t)3);
-            sh[k] = (uint32_t)(a0 & 3);
-        }
-        constexpr int NB = 5;                                   // (x 4 rows x 2 dwords: 40 registers; 128 registers = three workgroups per CU)
-        for (int base = 0; base < groups; base += NB * nt) {    // (one trip for sources up to 2 100 pixels wide)
-            uint32_t w0[4][NB], w1[4][NB];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!need[k]) continue;                         // (workgroup-uniform)
-                // the last dword that holds a byte of the row: no lane reads past it (lanes behind the row re-read it)
-                const int last = ((int)sh[k] + row_bytes - 1) >> 2;
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int gi = min(base + u * nt + t, groups - 1);
-                    w0[k][u] = al[k][gi];
-                    w1[k][u] = sh[k] ? al[k][min(gi + 1, last)] : 0u;      // (uniform condition)
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!need[k]) continue;
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int gi = base + u * nt + t;
-                    if (gi < groups) srows[k * src_row_dw + gi] = __builtin_amdgcn_alignbyte(w1[k][u], w0[k][u], sh[k]);
-                }
-            }
-        }
-    }
+    lut[t] = f32_to_st((float)t / 255.0f, f16);
     __syncthreads();
-    const uint32_t pad1 = lut[114];
-    // phase 2.  Two RGB pixels = six consecutive bytes at byte offset o of a staged source row: three aligned dwords, two
-    // v_alignbyte; channel c of both pixels as (p0 | p1 << 16) with one v_perm_b32, the horizontal pass p0 * a0 + p1 * a1
-    // with one v_dot2_u32_u16 -- integer arithmetic, the same values as the general kernel's products and sum.  (At the
-    // right edge x1 == x0 and a1 == 0: the bytes behind the row's last pixel are multiplied by zero.)
-    auto hpass = [&](const uint32_t* row, int o, uint32_t aw, uint32_t (&tc)[3]) __attribute__((always_inline)) {
-        const uint32_t* q = row + (o >> 2);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-        const uint32_t sh = (uint32_t)(o & 3);
-        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);            // bytes o .. o + 3
-        const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);            // bytes o + 4 .. o + 7
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        const u16x2 a2 = *(const u16x2*)&aw;
+    const int row_bytes = g.src_w * 3;
+    typedef const __attribute__((address_space(1))) uint8_t* gptr_t;
+    const uintptr_t src = (uintptr_t)g.src;
+    const long long image_bytes = (long long)g.src_h * row_bytes;
+    // columns: window start (byte offset in a row) and the packed weights of its two pixels
+    int wo[2];
+    uint32_t aw[2];
+    bool x_in[2];
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+        const int x = 2 * X + dx - g.left;
+        x_in[dx] = X < W2 && (unsigned)x < (unsigned)g.resized_w;
+        int x0 = 0, x1 = 0, a0 = 2048, a1 = 0;
+        if (x_in[dx]) linear_coef_s(x, g.sx, g.src_w, x0, x1, a0, a1);
+        const bool edge = x0 == g.src_w - 1 && g.src_w > 1;     // (then x1 == x0 and a1 == 0)
+        wo[dx] = (edge ? x0 - 1 : x0) * 3;
+        aw[dx] = edge ? ((uint32_t)a0 << 16) : ((uint32_t)a0 | ((uint32_t)a1 << 16));
+    }
+    // horizontal pass of source row r at window offset o: t[c] = p0[c] * a0 + p1[c] * a1.  The row's base address is scalar; a lane
+    // adds a 32-bit offset: the aligned dword address is  (base & ~3) + ((base & 3) + o & ~3),  the shift  (base & 3) + o & 3
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto hpass = [&](int r, int o, uint32_t w2, uint32_t (&tc)[3]) __attribute__((always_inline)) {
+        const long long row_off = (long long)r * row_bytes;                   // (scalar)
+        const uintptr_t base = src + (uintptr_t)row_off;
+        const uintptr_t base_al = base & ~(uintptr_t)3;
+        const uint32_t bo = (uint32_t)(base & 3) + (uint32_t)o;
+        const uint32_t voff = bo & ~3u, sh = bo & 3u;
+        // bytes from base_al to the end of the dword that holds the image's last byte (scalar; an image is far below 4 GB)
+        const uint32_t room = (uint32_t)((((src + (uintptr_t)image_bytes + 3) & ~(uintptr_t)3)) - base_al);
+        uint32_t lo, hi;
+        if (voff + 12u <= room && g.src_w > 1) {
+            typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+            const u32x3a w = *(const __attribute__((address_space(1))) u32x3a*)(base_al + voff);
+            lo = __builtin_amdgcn_alignbyte(w[1], w[0], sh);                   // bytes o .. o + 3
+            hi = __builtin_amdgcn_alignbyte(w[2], w[1], sh);                   // bytes o + 4 .. o + 7
+        } else {                                                               // the image's last bytes (or a one-pixel-wide source)
+            gptr_t q = (gptr_t)(base + (uintptr_t)o);
+            const int left = (int)(image_bytes - row_off - o);                 // bytes of the image from there on (>= 3)
+            lo = hi = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t v = k < left ? (uint32_t)q[k] : 0u;
+                if (k < 4) lo |= v << (8 * k); else hi |= v << (8 * (k - 4));
+            }
+        }
+        const u16x2 a2 = *(const u16x2*)&w2;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const uint32_t pp = __builtin_amdgcn_perm(hi, lo, (uint32_t)(c | (0x0c << 8) | ((c + 3) << 16) | (0x0cu << 24)));
             tc[c] = __builtin_amdgcn_udot2(*(const u16x2*)&pp, a2, 0u, false);
         }
     };
-    for (int xp = t; xp < W2; xp += nt) {                       // output columns 2 xp, 2 xp + 1
-        int x0[2];
-        uint32_t aw[2];
-        bool x_in[2];
+    // kLbRows space-to-depth rows per thread: the column weights above (a dozen double-precision instructions per column) are
+    // computed once for them, and the loads of the second row are in flight while the first is being finished
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int x = 2 * xp + dx - g.left;
-            x_in[dx] = (unsigned)x < (unsigned)g.resized_w;
-            int x1 = 0, a0 = 2048, a1 = 0;
-            x0[dx] = 0;
-            if (x_in[dx]) linear_coef_s(x, sx, g.src_w, x0[dx], x1, a0, a1);
-            aw[dx] = (uint32_t)a0 | ((uint32_t)a1 << 16);
-        }
-#pragma unroll
+    for (int rr = 0; rr < kLbRows; ++rr) {
+        const int Yr = Y * kLbRows + rr;
+        if (Yr >= H2) break;                                    // (workgroup-uniform)
+        // rows: weights of the two output rows and the source rows they need.  The values are the same in every lane (they depend on
+        // blockIdx only); v_readfirstlane says so to the compiler, which then keeps them -- and the row base addresses below -- in
+        // scalar registers
+        int ysrc[4] = {0, 0, 0, 0}, bw[4] = {2048, 0, 2048, 0};
+        bool y_in[2];
+    #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            uint32_t o16[6];
-            const uint32_t* r0 = srows + slot[2 * dy] * src_row_dw;
-            const uint32_t* r1 = srows + slot[2 * dy + 1] * src_row_dw;
-            const int b0 = bw[2 * dy], b1 = bw[2 * dy + 1];
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                uint32_t v[3] = {pad1, pad1, pad1};
-                if (y_in[dy] && x_in[dx]) {
-                    uint32_t t0[3], t1[3];
-                    hpass(r0, x0[dx] * 3, aw[dx], t0);
-                    hpass(r1, x0[dx] * 3, aw[dx], t1);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int o = (((b0 * (int)(t0[c] >> 4)) >> 16) + ((b1 * (int)(t1[c] >> 4)) >> 16) + 2) >> 2;
-                        v[c] = lut[min(max(o, 0), 255)];
-                    }
-                }
-                o16[3 * dx] = v[0]; o16[3 * dx + 1] = v[1]; o16[3 * dx + 2] = v[2];
-            }
-            uint32_t* dst = rows + dy * row_dw + 3 * xp;
-            dst[0] = o16[0] | (o16[1] << 16);
-            dst[1] = o16[2] | (o16[3] << 16);
-            dst[2] = o16[4] | (o16[5] << 16);
+            const int y = 2 * Yr + dy - g.top;
+            y_in[dy] = (unsigned)y < (unsigned)g.resized_h;
+            if (y_in[dy]) linear_coef_s(y, g.sy, g.src_h, ysrc[2 * dy], ysrc[2 * dy + 1], bw[2 * dy], bw[2 * dy + 1]);
         }
-    }
-    __syncthreads();
-    uint4* orow = (uint4*)(out + ((size_t)img * H2 + Y) * (size_t)W2 * 16);
-    const uint32_t* r0 = rows;
-    const uint32_t* r1 = rows + row_dw;
-    for (int q = t; q < 2 * W2; q += nt) {
-        const int X = q >> 1;
-        uint4 v;
-        if (q & 1) v = make_uint4(r1[3 * X + 1], r1[3 * X + 2], 0u, 0u);
-        else v = make_uint4(r0[3 * X], r0[3 * X + 1], r0[3 * X + 2], r1[3 * X]);
-        orow[q] = v;
+    #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ysrc[k] = __builtin_amdgcn_readfirstlane(ysrc[k]);
+            bw[k] = __builtin_amdgcn_readfirstlane(bw[k]);
+        }
+        uint32_t th[4][2][3];                                       // [source-row slot][dx][channel]
+    #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+    #pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                th[k][dx][0] = th[k][dx][1] = th[k][dx][2] = 0u;
+                if (y_in[k >> 1] && x_in[dx]) hpass(ysrc[k], wo[dx], aw[dx], th[k][dx]);
+            }
+        }
+        const uint32_t pad1 = lut[114];
+        uint32_t o16[2][6];
+    #pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int b0 = bw[2 * dy], b1 = bw[2 * dy + 1];
+    #pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+    #pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    uint32_t v = pad1;
+                    if (y_in[dy] && x_in[dx]) {
+                        // (24-bit multiplies: the weights are <= 2048, the passes' sums >> 4 below 2^15 -- the 32-bit multiply is quarter rate)
+                        const uint32_t t0 = th[2 * dy][dx][c], t1 = th[2 * dy + 1][dx][c];
+                        const int o = (int)(((__umul24((unsigned)b0, t0 >> 4) >> 16) + (__umul24((unsigned)b1, t1 >> 4) >> 16) + 2u) >> 2);
+                        v = lut[min(max(o, 0), 255)];
+                    }
+                    o16[dy][3 * dx + c] = v;
+                }
+            }
+        }
+        const uint4 v0 = make_uint4(o16[0][0] | (o16[0][1] << 16), o16[0][2] | (o16[0][3] << 16), o16[0][4] | (o16[0][5] << 16), o16[1][0] | (o16[1][1] << 16));
+        const uint4 v1 = make_uint4(o16[1][2] | (o16[1][3] << 16), o16[1][4] | (o16[1][5] << 16), 0u, 0u);
+        // wave-private transpose: lane l holds chunks 2l, 2l + 1 of its wave's 128 consecutive 16-byte chunks; it stores chunks l and 64 + l
+        const int lane = t & 63, wv = t >> 6;
+        uint4* st = stage + wv * 128;
+        st[2 * lane] = v0;
+        st[2 * lane + 1] = v1;
+        __builtin_amdgcn_wave_barrier();
+        const uint4 c0 = st[lane], c1 = st[64 + lane];
+        // (the wave's s2d pixels X0 .. X0 + 63; those at or behind W2 belong to no row of this image)
+        const int X0 = blockIdx.x * 256 + wv * 64;
+        uint4* dst = (uint4*)(out + (((size_t)img * H2 + Yr) * W2 + X0) * 16);
+        if (X0 + (lane >> 1) < W2) dst[lane] = c0;
+        if (X0 + 32 + (lane >> 1) < W2) dst[64 + lane] = c1;
     }
 }
 
 // which kernel a batch takes: 1 = streaming copy (no image is resampled), 2 = streaming bilinear (every resampled image with
 // cv2.INTER_LINEAR, source rows short enough for the LDS), 0 = the general kernel (INTER_AREA, very wide sources, odd widths)
-struct LbPlan { int kind; int src_row_dw; size_t lds; };
+struct LbPlan { int kind; size_t lds; };
 static LbPlan lb_plan(const LetterboxDev* g, int n, int out_w, bool force_general) {
-    LbPlan p{0, 0, 0};
-    if (force_general || (out_w % 4) != 0) return p;
+    LbPlan p{0, 0};
+    if (force_general) return p;
     bool no_resampling = true, linear = true;
-    int max_src_w = 0;
     for (int i = 0; i < n; ++i) {
         const bool rs = g[i].resized_h != g[i].src_h || g[i].resized_w != g[i].src_w;
         no_resampling = no_resampling && !rs;
         linear = linear && (!rs || g[i].interp == 0);
-        max_src_w = std::max(max_src_w, g[i].src_w);
     }
     if (no_resampling) {
         p.lds = 512 + (size_t)out_w * 12;
-        if (p.lds <= 65536) p.kind = 1;
+        if ((out_w % 4) == 0 && p.lds <= 65536) p.kind = 1;
+        else p.kind = 2;                                       // (the bilinear kernel with unit weights: exact)
         return p;
     }
-    if (linear && max_src_w <= kLbLinMaxSrcW) {
-        p.src_row_dw = (max_src_w * 3 + 3) / 4 + 4;            // + the dwords six() reads behind the last pixel
-        p.lds = 512 + (size_t)out_w * 12 + (size_t)p.src_row_dw * 16;
-        if (p.lds <= 65536) p.kind = 2;
-    }
+    if (linear) p.kind = 2;
     return p;
 }
 bool letterbox_geometry_travels_inline(const LetterboxDev* geom_host, int n, int out_w, bool force_general) {
@@ -465,11 +449,10 @@ hipError_t launch_letterbox_s2d(const LetterboxDev* geom_dev, const LetterboxDev
         if (n <= kLbInline) {
             geom.ptr = nullptr;
             for (int i = 0; i < n; ++i) geom.inl[i] = geom_host[i];
-            for (int i = n; i < kLbInline; ++i) geom.inl[i] = LetterboxDev{nullptr, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = n; i < kLbInline; ++i) geom.inl[i] = LetterboxDev{nullptr, 0, 0, 0, 0, 0, 0, 0, 1.0, 1.0};
         }
         if (plan.kind == 1) hipLaunchKernelGGL(letterbox_copy_s2d_kernel, dim3(H2, n), dim3(256), plan.lds, s, geom, out_h, out_w, out, f16);
-        else hipLaunchKernelGGL(letterbox_linear_s2d_kernel, dim3(H2, n), dim3((W2 % kLbLinThreads) == 0 ? kLbLinThreads : 256), plan.lds, s,
-                                geom, out_h, out_w, plan.src_row_dw, out, f16);
+        else hipLaunchKernelGGL(letterbox_linear_s2d_kernel, dim3((W2 + 255) / 256, (H2 + kLbRows - 1) / kLbRows, n), dim3(256), 0, s, geom, out_h, out_w, out, f16);
         return hipGetLastError();
     }
     dim3 grid((W2 + 255) / 256, H2, n);
