@@ -716,7 +716,7 @@ def main():
         scale_px = (Hn * Wn) / (1280.0 * 1280.0)
         src_bytes = H0 * W0 * 3 + Hn * Wn * 3 * 2           # uint8 source read + 16-bit network input written
         roof['stages'] = {
-            'preprocess': stage(src_bytes, live_pre, 'letterbox_s2d_kernel, live events, {} steps'.format(len(live_pre))),
+            'preprocess': stage(src_bytes, live_pre, 'letterbox kernel of the batch (streaming copy: no resampling; streaming bilinear: INTER_LINEAR; general otherwise), live events, {} steps'.format(len(live_pre))),
             'nms': stage(NMS_BYTES_PER_IMAGE * scale_px, live_nms,
                          'nms kernels + D2H of the results, live events on the NMS stream, {} steps'.format(len(live_nms))),
             'decode': None if args.lean else stage(

@@ -3,7 +3,7 @@
 # profiles/README.md cite).  usage (build container, after the gpurun call returned):  ROUND=5 bash tools/collect_final.sh
 set -u
 cd "$(dirname "$0")/.."
-R=${ROUND:-5}
+R=${ROUND:-6}
 F=gpurun_out/final$R
 P=profiles/r$R
 j() { grep '^{' "$1" | tail -1; }
@@ -31,6 +31,10 @@ cp $F/ops_b32.json ${P}_ops_b32.json
 cp $F/ops_fp8_b64.json ${P}_ops_fp8_b64.json
 [ -s $F/hbm_traffic.json ] || python tools/hbm_traffic.py $F/traffic_FETCH_SIZE $F/traffic_WRITE_SIZE YOLOV5X6_MD:32:1280 $F/hbm_traffic.json
 cp $F/hbm_traffic.json ${P}_hbm_traffic.json
+[ -s $F/hbm_traffic_by_kernel.txt ] && cp $F/hbm_traffic_by_kernel.txt ${P}_hbm_traffic_by_kernel.txt
+[ -s $F/l2_hit_rate_by_kernel.txt ] && grep -v amdgpu $F/l2_hit_rate_by_kernel.txt > ${P}_l2_hit_rate_by_kernel.txt
+[ -s $F/bench_8rank_one_gpu_gloo.log ] && j $F/bench_8rank_one_gpu_gloo.log > ${P}_bench_8rank_one_gpu_gloo.json
+[ -s $F/letterbox_bench.txt ] && grep -v amdgpu $F/letterbox_bench.txt > ${P}_letterbox_final_session.txt
 cp gpurun_out/pmc_final$R.txt ${P}_pmc_bench_kernels.txt
 cp gpurun_out/pmc_final$R.json ${P}_pmc_bench_kernels.json
 cp $F/e2e_feed.json ${P}_e2e_feed.json

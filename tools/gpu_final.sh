@@ -9,7 +9,7 @@ R=${ROUND:-6}
 O=gpurun_out/final$R
 mkdir -p $O
 export TMPDIR=/tmp
-T0=$(date +%s); T_MAX=${T_MAX:-900}
+T0=$(date +%s); T_MAX=${T_MAX:-1300}
 left() { [ $(( $(date +%s) - T0 )) -lt $T_MAX ]; }
 stamp() { echo "$1 at $(( $(date +%s) - T0 )) s" >> $O/timing.log; }
 (rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -6; nproc) > $O/env.txt 2>&1
@@ -40,7 +40,23 @@ done
 python tools/hbm_traffic.py $O/traffic_FETCH_SIZE $O/traffic_WRITE_SIZE YOLOV5X6_MD:32:1280 $O/hbm_traffic.json $O/ops_b32.json $O/hbm_traffic_by_kernel.txt > $O/hbm_traffic.log 2>&1
 # (the per-dispatch CSVs are kept when small enough: they are what the per-op alignment reads)
 find $O/traffic_FETCH_SIZE $O/traffic_WRITE_SIZE -type f -size +8M -delete 2>/dev/null
-stamp "trace + traffic"
+# L2 hit rate per kernel (why the reads are 1.6x the algorithmic bytes: VERDICT r5 item 3): its own counters-only pass
+(cd /tmp && timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d "$RP/$O/tcc" -o t --output-format csv -- \
+   python "$RP/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --lean > "$RP/$O/tcc.log" 2>&1)
+python - "$O/tcc" > $O/l2_hit_rate_by_kernel.txt 2>&1 <<'PY'
+import collections, csv, glob, re, sys
+acc = collections.defaultdict(lambda: [0.0, 0.0, 0])
+for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').replace('mdhip::st_bf16::', '').replace('mdhip::', '')
+        if r['Counter_Name'] == 'TCC_HIT_sum': acc[name][0] += float(r['Counter_Value']); acc[name][2] += 1
+        if r['Counter_Name'] == 'TCC_MISS_sum': acc[name][1] += float(r['Counter_Value'])
+print('# L2 (TCC) hit rate per kernel instantiation over a 3-step bench run (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum, counters only): hits / (hits + misses)')
+for name, (h, m, n) in sorted(acc.items(), key=lambda kv: -(kv[1][0] + kv[1][1])):
+    if h + m > 0: print('{:7.4f}  {:12.0f} requests per dispatch  {:4d} dispatches  {}'.format(h / (h + m), (h + m) / max(n, 1), n, name))
+PY
+find $O/tcc -type f -size +1M -delete 2>/dev/null
+stamp "trace + traffic + L2 hit rate"
 left && { bash tools/pmc_bench.sh final$R > $O/pmc_bench.log 2>&1; cp gpurun_out/pmc_final$R.txt gpurun_out/pmc_final$R.json $O/ 2>/dev/null; }
 stamp "pmc"
 left && timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs --src 1536x2048 > $O/bench_real43.log 2>&1
@@ -62,6 +78,9 @@ left && MDHIP_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnod
 # the self-launching form (`python bench.py --gpus 2`, no launcher) and a pinned single-GPU run (placement.pin_worker(force))
 left && MDHIP_BENCH_ONE_GPU=1 timeout 300 python bench.py --gpus 2 --batch 8 --steps 30 --warmup 5 > $O/bench_selflaunch_2rank.log 2> $O/bench_selflaunch_2rank.err
 left && timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs --pin-cpus > $O/bench_pinned.log 2> $O/bench_pinned.err
+left && MDHIP_BENCH_ONE_GPU=1 timeout 400 python bench.py --gpus 8 --batch 2 --steps 20 --warmup 3 > $O/bench_8rank_one_gpu_gloo.log 2> $O/bench_8rank_one_gpu_gloo.err
+left && timeout 200 python tools/letterbox_bench.py > $O/letterbox_bench.txt 2>&1
+left && MDHIP_POOL_CH4=1 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-configs --profile-out $O/ops_b32_pool_ch4.json > $O/bench_pool_ch4.log 2>&1
 left && timeout 400 python tools/e2e_feed_bench.py --n 4096 --workers 16,24 --out $O/e2e_feed.json > $O/e2e_feed.log 2>&1
 # the NUMA placement code on this box's topology (8 GPUs asked for: what the planner does with the GPUs it cannot see)
 left && python -c "
