@@ -105,6 +105,19 @@ conv_v7_kernel(const ConvArgs p) {
     const int G = p.groups;                       // 64-channel groups (the last one may be partly full)
     const int runs_per_tile = 3 * G;
     const int total_runs = my_tiles * runs_per_tile;
+    // [r6] developer switch (p.dev_param == 66; measured, not the default): every other tile of an image walks its kernel rows
+    // BACKWARDS (r = 2, 1, 0 inside every channel group).  The input row below a tile's last output row is read by that tile's
+    // kernel row 2 and by the next tile's kernel row 0; the two tiles run at the same time on neighbouring CUs of one XCD, but in
+    // the common order the first reads it in the last third of a group's nine steps and the second in the first third -- six steps
+    // apart, by which time the XCD has streamed twice its L2.  With alternating directions both read a shared row in the same
+    // third: FETCH_SIZE of layer 1 falls by 20 % (5.03 -> 4.01 GB), of layer 3 by 11 % -- and the launches take the same time
+    // (L1 + 2 %, L3 - 1.4 %, L5 / L7 / L24 / L27 +- 0.5 %; profiles/r6_read_amplification.txt): these layers are not bound by
+    // their reads.  Since it would change the summation order of every second tile for nothing, the common order stays.  (The
+    // parity is that of the tile's index INSIDE its image, so a pixel's order would not depend on its batch; tiles that straddle
+    // images keep the common order.)
+    const bool rev_on = (p.HoWo % BM) == 0 && p.dev_param == 66;
+    const int tpi = rev_on ? p.HoWo / BM : 1;      // tiles per image
+    auto tile_rev = [&](int t) __attribute__((always_inline)) -> bool { return rev_on && ((t % tpi) & 1) != 0; };
 
     if (tid < 16) *(__attribute__((address_space(3))) uint4*)(smem + ZERO_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
     if constexpr (AL) {
@@ -122,7 +135,10 @@ conv_v7_kernel(const ConvArgs p) {
         (void*)(p.wgt4 + (size_t)n0 * p.k_pad4), 0, kNumRecords, 0x00020000);
     const unsigned b_off = (unsigned)((wave * 8 + lr) * p.k_pad4 + jj * 8) * 2u;
     const unsigned b_stride = (unsigned)(NW * 8 * p.k_pad4) * 2u;
-    int l_base = 0, l_j = 0;                       // the loader's slab: l_base = 9 * group + 3 * r, l_j = 0 / 1 / 2 -> tap 0 / 2 / 1
+    int l_base = 0, l_j = 0;                       // the loader's slab: l_base = 9 * group + 3 * (kernel row), l_j = 0 / 1 / 2 -> tap 0 / 2 / 1
+    int l_g = 0, l_r = 0, l_tile = first_tile;     // its group, its position in the tile's kernel-row walk, its tile
+    bool l_rev = tile_rev(first_tile);
+    l_base = l_rev ? 6 : 0;
     auto dma_b_piece = [&](int stage, int i) __attribute__((always_inline)) {
         if ((B_PIECES % NW) != 0 && i == B_PER - 1 && wave >= B_PIECES % NW) return;           // wave-uniform
         const int slab = l_base + (l_j == 0 ? 0 : (l_j == 1 ? 2 : 1));
@@ -133,8 +149,15 @@ conv_v7_kernel(const ConvArgs p) {
     auto dma_b_done = [&]() __attribute__((always_inline)) {
         if (++l_j == 3) {
             l_j = 0;
-            l_base += 3;
-            if (l_base == 9 * G) l_base = 0;
+            if (++l_r == 3) {
+                l_r = 0;
+                if (++l_g == G) {
+                    l_g = 0;
+                    l_tile += tile_step;                   // (past the stream's last tile: slabs nobody reads)
+                    l_rev = tile_rev(l_tile);
+                }
+            }
+            l_base = 9 * l_g + 3 * (l_rev ? 2 - l_r : l_r);
         }
     };
 
@@ -156,6 +179,7 @@ conv_v7_kernel(const ConvArgs p) {
     int lg_tile = first_tile, lg_cg = 0, lg_r = 0;
     int lg_px0 = 0;                                 // input pixel index of (b, 2 oy - 1, 2 ox_w) relative to the descriptor (may be negative)
     bool lg_top = false, lg_ok = false;             // oy > 0 ; the wave's row exists (inside the batch)
+    bool lg_rev = false;                            // the loader's tile walks its kernel rows backwards
     __amdgpu_buffer_rsrc_t lg_rsrc = b_rsrc;
     const long long img_bytes = (long long)p.H * p.W * p.ld_in * 2;
     const int n_img = p.M / p.HoWo;
@@ -173,12 +197,14 @@ conv_v7_kernel(const ConvArgs p) {
         const int ox = rem - oy * p.Wo;
         lg_top = oy > 0;
         lg_px0 = ((b - b0) * p.H + 2 * oy - 1) * p.W + 2 * ox;
+        lg_rev = tile_rev(lg_tile);
     };
     auto run_geom = [&]() __attribute__((always_inline)) -> RunGeom {
         RunGeom g;
         g.rsrc = lg_rsrc;
-        const bool ok = lg_ok && (lg_r > 0 || lg_top);
-        const unsigned base = (unsigned)(lg_px0 + lg_r * p.W) * (unsigned)p.ld_in * 2u + (unsigned)(lg_cg * 128);
+        const int re = lg_rev ? 2 - lg_r : lg_r;                          // the kernel row of this position of the walk
+        const bool ok = lg_ok && (re > 0 || lg_top);
+        const unsigned base = (unsigned)(lg_px0 + re * p.W) * (unsigned)p.ld_in * 2u + (unsigned)(lg_cg * 128);
         g.so_e = ok ? base : kOOB;
         g.so_o = ok ? base + (unsigned)p.ld_in * 2u : kOOB;
         g.tail = TAIL != 0 && lg_cg == G - 1 && (p.C8 & 7) != 0;
@@ -367,14 +393,15 @@ conv_v7_kernel(const ConvArgs p) {
     __builtin_amdgcn_s_barrier();
 
     frag8_t xa[FM], wa[FN], xb[FM], wb[FN];
+    bool c_rev = tile_rev(first_tile);             // the consumer's tile walks its kernel rows backwards
     if constexpr (AL) {
         wave_flags(first_tile);
-        al_x_addresses(0, 0);
+        al_x_addresses(c_rev ? 2 : 0, 0);
     } else {
         tile_masks(first_tile);
         const unsigned a0 = a_shift_now(-1) + (unsigned)O_OFF;
 #pragma unroll
-        for (int i = 0; i < FM; ++i) set_a_eff_one(0, 0, i, a0);
+        for (int i = 0; i < FM; ++i) set_a_eff_one(c_rev ? 2 : 0, 0, i, a0);
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i) xa[i] = read_x(i, 0);
@@ -390,12 +417,14 @@ conv_v7_kernel(const ConvArgs p) {
         const bool skip_y = tail_short && c_cg == G - 1;
         const bool tile_end = c_r == 2 && c_cg == G - 1;
         const int n_r = c_r == 2 ? 0 : c_r + 1;
+        const bool n_rev = tile_end ? tile_rev(c_tile + tile_step) : c_rev;     // (of the run after this one)
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
             const int cur = step & 1;
-            // the step being prefetched: tap 2 / tap 1 of this kernel row, or tap 0 of the next run
+            // the step being prefetched: tap 2 / tap 1 of this kernel row, or tap 0 of the next run; nr = its KERNEL ROW (a
+            // backward tile's walk position w is kernel row 2 - w)
             const int nst = st == 2 ? 0 : st + 1;
-            const int nr = st == 2 ? n_r : c_r;
+            const int nr = st == 2 ? (n_rev ? 2 - n_r : n_r) : (c_rev ? 2 - c_r : c_r);
             unsigned a_next = 0;
             if constexpr (AL) {
                 al_by = al_bx ^ 64u;                                       // the k 32..63 addresses of THIS step
@@ -455,6 +484,7 @@ conv_v7_kernel(const ConvArgs p) {
         run_next();
         g_nxt = run_geom();
         c_r = n_r;
+        c_rev = n_rev;
         if (n_r == 0 && ++c_cg == G) {
             c_cg = 0;
             epilogue(c_tile);
