@@ -719,11 +719,24 @@ def main():
             'preprocess': stage(src_bytes, live_pre, 'letterbox kernel of the batch (streaming copy: no resampling; streaming bilinear: INTER_LINEAR; general otherwise), live events, {} steps'.format(len(live_pre))),
             'nms': stage(NMS_BYTES_PER_IMAGE * scale_px, live_nms,
                          'nms kernels + D2H of the results, live events on the NMS stream, {} steps'.format(len(live_nms))),
-            'decode': None if args.lean else stage(
-                DECODE_BYTES_PER_IMAGE * scale_px, [float(sum(ms[o['op']] for o in infos if o['kind'] == 3))],
-                'detect_decode_kernel x{} levels, per-op events outside the timed region'.format(
-                    sum(1 for o in infos if o['kind'] == 3))),
+            'decode': None,
         }
+        if not args.lean:
+            dec_ops = [o for o in infos if o['kind'] == 3]
+            folded = [o for o in dec_ops if o['cfg'] == -2]          # decoded in the epilogue of the conv in front (mdhip.h)
+            if folded and len(folded) == len(dec_ops):
+                # no decode launch exists: the stage IS the Detect 1x1 convs (read the level's feature map, write the fp32
+                # predictions); bytes = those convs' algorithmic bytes, per batch
+                det = [infos[o['op'] - 1] for o in dec_ops]
+                roof['stages']['decode'] = stage(
+                    sum(o['bytes'] for o in det) / B, [float(sum(ms[o['op']] for o in det))],
+                    'Detect 1x1 conv + decode in one launch x{} levels (no detect_decode_kernel launch, no fp32 logits tensor): '
+                    'feature map read + predictions written, per-op events outside the timed region'.format(len(det)))
+            else:
+                roof['stages']['decode'] = stage(
+                    DECODE_BYTES_PER_IMAGE * scale_px, [float(sum(ms[o['op']] for o in dec_ops if o['cfg'] != -2))],
+                    'detect_decode_kernel x{} levels, per-op events outside the timed region'.format(
+                        sum(1 for o in dec_ops if o['cfg'] != -2)))
         if args.model == 'YOLOV5X6_MD' and (Hn, Wn) == (1280, 1280):
             assert abs(conv_flops / B / 1e9 - GFLOP_PER_IMAGE_1280) < 0.05, conv_flops / B / 1e9
         if args.profile_out and not args.lean:

@@ -204,7 +204,8 @@ typedef struct {
     int32_t m, n, k;        /* GEMM view of a conv (per call, for the last n,h,w) */
     double  flops;          /* algorithmic FLOPs of the op for the last (n,h,w)   */
     double  bytes;          /* algorithmic HBM bytes (read input once + write output once + weights) */
-    int32_t cfg;            /* tile configuration chosen                      */
+    int32_t cfg;            /* tile configuration chosen (a decode op: -2 = done in
+                             * the epilogue of the conv in front, -1 = own launch) */
     int32_t ntaps, stride, has_res;   /* conv: kh*kw of the packed kernel, stride, residual added */
 } mdhip_op_info;
 

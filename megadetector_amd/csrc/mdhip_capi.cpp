@@ -1090,8 +1090,10 @@ int run_op(mdhip_ctx* ctx, Op& op, int n, int h, int w, hipStream_t s) {
         case OP_DECODE: {
             if (op.dec_done) {                     // decoded in the epilogue of the conv in front (this forward)
                 op.bytes = 0;
+                op.last_cfg = -2;                  // (mdhip_get_op_info: -2 = folded into the conv in front, -1 = own launch)
                 break;
             }
+            op.last_cfg = -1;
             const int ny = h / op.in.div, nx = w / op.in.div;
             int level_off = 0;
             for (int l = 0; l < op.level; ++l) {
