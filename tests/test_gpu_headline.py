@@ -427,7 +427,8 @@ def test_fused_bottleneck_is_bit_identical_to_the_two_launches(dtype):
     for (n, hh, ww) in ((1, 1280, 1280), (3, 384, 640), (2, 256, 384), (2, 128, 192)):
         ctx = HipContext(W, device=0, dtype=dtype, max_batch=n, max_h=hh, max_w=ww)
         try:
-            strip = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith('v5:strip')][0]
+            strips = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith('v5:strip')]
+            strip = strips[0]
             imgs = PU.random_images(n, hh, ww, seed=2 * hh + ww)
             ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
             ops = [o['op'] for o in ctx.op_infos() if o['kind'] == 0 and ctx.op_supports_cfg(o['op'], strip)]
@@ -449,6 +450,25 @@ def test_fused_bottleneck_is_bit_identical_to_the_two_launches(dtype):
             np.testing.assert_array_equal(ctx.read_predictions(n), ref_pred)
             ctx.forward_tta(n, hh, ww)
             np.testing.assert_array_equal(ctx.read_predictions(n), ref_tta)
+            # every other strip configuration (the four-row fused kernel among them): the same bits, fused, plain and augmented
+            for other in strips[1:]:
+                for op in ops:
+                    ctx.set_op_cfg(op, other)
+                ctx.forward(n, hh, ww)
+                skipped = [o['name'] for o in ctx.op_infos() if o['kind'] == 0 and o['cfg'] < 0]
+                assert len(skipped) == 4, (ctx.conv_cfg_name(other), skipped)
+                np.testing.assert_array_equal(ctx.read_layer(2, n), ref_l2, err_msg=ctx.conv_cfg_name(other))
+                np.testing.assert_array_equal(ctx.read_predictions(n), ref_pred, err_msg=ctx.conv_cfg_name(other))
+                ctx.forward_tta(n, hh, ww)
+                np.testing.assert_array_equal(ctx.read_predictions(n), ref_tta, err_msg=ctx.conv_cfg_name(other))
+                if n > 1:                                                                 # batch invariance, fused
+                    ctx.preprocess([imgs[n - 1]], _identity_geoms([imgs[n - 1]]), hh, ww)
+                    ctx.forward(1, hh, ww)
+                    np.testing.assert_array_equal(ctx.read_predictions(1)[0], ref_pred[n - 1], err_msg=ctx.conv_cfg_name(other))
+                    ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
+            for op in ops:
+                ctx.set_op_cfg(op, strip)
+            ctx.forward(n, hh, ww)
             if n > 1:                                                                     # batch invariance, fused
                 ctx.preprocess([imgs[n - 1]], _identity_geoms([imgs[n - 1]]), hh, ww)
                 ctx.forward(1, hh, ww)

@@ -235,6 +235,34 @@ int main(int argc, char** argv) {
                            sh->s, pad, k_pad, cin_pad);
         CK(hipDeviceSynchronize());
     }
+    // CONVBENCH_FUSED=1 (80 -> 80 channel 3x3 shapes): the whole bottleneck out = x + SiLU(W2 * SiLU(W1 x + b1) + b2) in one
+    // launch (conv_v5c.cpp's fused kernels: ConvArgs::wgt_pre / bias_pre, residual = the input); the reference is the two
+    // reference convs in a row with the hidden tensor rounded to 16 bits in between
+    const bool fused = getenv("CONVBENCH_FUSED") && atoi(getenv("CONVBENCH_FUSED")) != 0;
+    uint16_t *d_wpre = nullptr, *d_hidden = nullptr;
+    float* d_bpre = nullptr;
+    const int k_pad_pre = (cin_pad + 63) / 64 * 64;
+    if (fused) {
+        if (sh->k != 3 || sh->s != 1 || sh->cin != sh->cout) { fprintf(stderr, "CONVBENCH_FUSED: a C -> C 3x3 / s1 shape\n"); return 2; }
+        std::vector<uint16_t> h_wpre((size_t)n_rows * k_pad_pre, 0);
+        std::vector<float> h_bpre(n_rows, 0.f);
+        const float ws1 = 1.0f / sqrtf((float)sh->cin);
+        for (int n = 0; n < sh->cout; ++n) {
+            h_bpre[n] = 0.1f * nd(rng);
+            for (int c = 0; c < sh->cin; ++c) h_wpre[(size_t)n * k_pad_pre + c] = f32_to_bf16(ws1 * nd(rng));
+        }
+        CK(hipMalloc(&d_wpre, h_wpre.size() * 2));
+        CK(hipMalloc(&d_bpre, n_rows * 4));
+        CK(hipMalloc(&d_hidden, in_elems * 2 + 4096));
+        CK(hipMemcpy(d_wpre, h_wpre.data(), h_wpre.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_bpre, h_bpre.data(), n_rows * 4, hipMemcpyHostToDevice));
+        const long long total = M * sh->cout;
+        hipLaunchKernelGGL(ref_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, d_in, d_wpre, d_bpre,
+                           (const uint16_t*)nullptr, d_hidden, sh->b, sh->h, sh->w, sh->cin, sh->h, sh->w, sh->cout, 1, 1, 0, k_pad_pre, cin_pad);
+        hipLaunchKernelGGL(ref_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, d_hidden, d_w, d_b,
+                           sh->res ? d_in : nullptr, d_ref, sh->b, sh->h, sh->w, sh->cin, Ho, Wo, sh->cout, sh->k, sh->s, pad, k_pad, cin_pad);
+        CK(hipDeviceSynchronize());
+    }
     std::vector<uint16_t> h_ref16(out_elems), h_out(out_elems);
     CK(hipMemcpy(h_ref16.data(), d_ref, out_elems * 2, hipMemcpyDeviceToHost));
 
@@ -289,7 +317,11 @@ int main(int argc, char** argv) {
     a.stride = sh->s; a.pad = pad; a.act = 1; a.out_f32 = 0;
     a.wgt4 = d_w4; a.k_pad4 = k_pad4; a.groups = groups;
     a.wgt4p = d_w4p; a.k_pad4p = k_pad4p;
-    const double flops = 2.0 * (double)M * sh->cout * k_real;
+    if (fused) {
+        a.wgt_pre = d_wpre; a.bias_pre = d_bpre; a.k_pad_pre = k_pad_pre;
+        a.res = sh->res ? d_in : nullptr; a.ld_res = sh->cin;
+    }
+    const double flops = 2.0 * (double)M * sh->cout * (k_real + (fused ? sh->cin : 0));
     const size_t dbg_words = 8 * 16 * 4096;
     unsigned long long* d_dbg;
     CK(hipMalloc(&d_dbg, dbg_words * 8));
@@ -340,6 +372,26 @@ int main(int argc, char** argv) {
         printf("  cfg %2d %-22s %8.4f ms (best %8.4f)  %7.1f TF/s   max|err| %.3g (max|ref| %.3g) bad %zu%s\n", cfg,
                cfg <= -801 ? conv8_cfg(conv8_num_cfgs() - 801 - cfg).name : cfg <= -401 ? conv6_cfg(conv6_num_cfgs() - 401 - cfg).name : cfg <= -301 ? conv5_cfg(conv5_num_cfgs() - 301 - cfg).name : cfg < 0 ? conv2_cfg(conv2_num_cfgs() - 1 - cfg).name : conv_cfg(cfg).name, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, max_err, max_ref, bad,
                bad ? "  <-- MISMATCH" : "");
+        if (cfg >= 0 && !strncmp(conv_cfg(cfg).name, "dev:strip", 9)) {
+            // the stamped four-row fused bottleneck: cycles per tile and wave by phase
+            std::vector<unsigned long long> h(dbg_words);
+            CK(hipMemcpy(h.data(), d_dbg, dbg_words * 8, hipMemcpyDeviceToHost));
+            double sum[6] = {0, 0, 0, 0, 0, 0}, tiles = 0;
+            int waves = 0;
+            for (size_t w = 0; w < dbg_words / 8; ++w) {
+                if (!h[w * 8 + 6]) continue;
+                ++waves;
+                tiles += (double)h[w * 8 + 6];
+                for (int k = 0; k < 6; ++k) sum[k] += (double)h[w * 8 + k];
+            }
+            static const char* nm[6] = {"pass 1 (64-channel group)", "pass 2 (16-channel group)", "epilogue + weight reload", "wait (DMA) + barrier",
+                                        "conversion of the next T rows", "barrier + DMA issue, unit start-up"};
+            double tot = 0;
+            for (int k = 0; k < 6; ++k) tot += sum[k];
+            printf("    %d waves, %.1f tiles each; cycles per tile: total %.0f\n", waves, tiles / std::max(1, waves), tot / std::max(1.0, tiles));
+            for (int k = 0; k < 6; ++k) printf("      %-36s %8.1f  (%4.1f%%)\n", nm[k], sum[k] / std::max(1.0, tiles), 100 * sum[k] / std::max(1.0, tot));
+            CK(hipMemset(d_dbg, 0, dbg_words * 8));
+        }
         if (cfg < 0) {
             // per-wave phase sums of the last launch: cycles per step, averaged over all waves that ran
             std::vector<unsigned long long> h(dbg_words);
