@@ -820,6 +820,7 @@ conv_c80d_kernel(const ConvArgs p) {
             unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 10 + wave) * 8;
             for (int k = 0; k < 6; ++k) d[k] = t_acc[k];
             d[6] = n_tiles;
+            d[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((6 - 1) << 11) | (0 << 6) | 4) | 0x100;   // HW_REG_HW_ID[5:0]: wave slot [3:0], SIMD [5:4]
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__

@@ -366,9 +366,9 @@ def test_row_patch_conv_matches_implicit_gemm_and_oracle():
         convs = [o['op'] for o in ctx.op_infos() if o['kind'] == 0]
         # (the e4m3 family f8:* takes fp8 operands only: tests/test_gpu_fp8.py; the strip kernel v5:strip* takes the
         # 80 -> 80 channel layers of the x6 stack only, the stride-2 row-run kernel v7:* layers with a multiple of 160
-        # output channels only: tests/test_gpu_headline.py)
+        # output channels only: tests/test_gpu_headline.py; dev:* are stamped developer variants that run only from tools/convbench)
         patch_cfgs = [c for c in range(ctx.num_conv_cfgs())
-                      if not ctx.cfg_is_bitwise(c) and not ctx.conv_cfg_name(c).startswith(('f8:', 'v5:strip', 'v7:') + EIGHT_WAVE_TILES)]
+                      if not ctx.cfg_is_bitwise(c) and not ctx.conv_cfg_name(c).startswith(('f8:', 'v5:strip', 'dev:', 'v7:') + EIGHT_WAVE_TILES)]
         assert patch_cfgs, 'no row-patch configuration in this build'
         x, _ = PU.oracle_input(imgs, WW, 64)
         assert tuple(x.shape[2:]) == (HH, WW)

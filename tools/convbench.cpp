@@ -388,6 +388,23 @@ int main(int argc, char** argv) {
                                         "conversion of the next T rows", "barrier + DMA issue, unit start-up"};
             double tot = 0;
             for (int k = 0; k < 6; ++k) tot += sum[k];
+            {   // which SIMD each wave index of a workgroup sits on (HW_ID[5:4]); and the phase cycles by wave index
+                int hist[10][4] = {};
+                for (size_t w = 0; w < dbg_words / 8; ++w)
+                    if (h[w * 8 + 7]) ++hist[w % 10][(h[w * 8 + 7] >> 4) & 3];
+                printf("    SIMD of wave index 0..9 (workgroups per SIMD id 0/1/2/3):");
+                for (int k = 0; k < 10; ++k) printf("  %d:%d/%d/%d/%d", k, hist[k][0], hist[k][1], hist[k][2], hist[k][3]);
+                printf("\n");
+                for (int k = 0; k < 10; ++k) {
+                    double s6[6] = {0, 0, 0, 0, 0, 0}, tl = 0;
+                    for (size_t w = k; w < dbg_words / 8; w += 10) {
+                        if (!h[w * 8 + 6]) continue;
+                        tl += (double)h[w * 8 + 6];
+                        for (int q = 0; q < 6; ++q) s6[q] += (double)h[w * 8 + q];
+                    }
+                    if (tl > 0) printf("      wave %d: %7.0f %7.0f %7.0f %7.0f %7.0f %7.0f\n", k, s6[0] / tl, s6[1] / tl, s6[2] / tl, s6[3] / tl, s6[4] / tl, s6[5] / tl);
+                }
+            }
             printf("    %d waves, %.1f tiles each; cycles per tile: total %.0f\n", waves, tiles / std::max(1, waves), tot / std::max(1.0, tiles));
             for (int k = 0; k < 6; ++k) printf("      %-36s %8.1f  (%4.1f%%)\n", nm[k], sum[k] / std::max(1.0, tiles), 100 * sum[k] / std::max(1.0, tot));
             CK(hipMemset(d_dbg, 0, dbg_words * 8));
