@@ -558,9 +558,10 @@ hipError_t launch_sppf_pool(uint16_t* buf, int ld, int c, int n, int h, int w, i
     const size_t per_chunk = (size_t)h * w * 16 * 2;                // two LDS buffers of one 8-channel chunk of the map
     if (per_chunk * 4 <= 65536) {
         // [r6] two chunks (16 channels) per workgroup when that still gives a thread per item: twice the workgroups, each
-        // with half the passes' work -- the kernel is bound by its six barrier-separated passes, not by bytes
+        // with half the passes' work.  Measured against four chunks in one session: 0.0935 / 0.0947 ms at batch 32 -- no
+        // difference: the kernel is bound by its six barrier-separated passes either way (profiles/r6_read_amplification.txt)
         const int items2 = h * w * 2;
-        if (items2 >= 512 && items2 <= 1024 && getenv("MDHIP_POOL_CH4") == nullptr) {
+        if (items2 >= 512 && items2 <= 1024) {
             hipLaunchKernelGGL(sppf_pool_lds_kernel<2>, dim3((unsigned)(n * ((c / 8 + 1) / 2))), dim3((items2 + 63) / 64 * 64), per_chunk * 2, s,
                                buf, ld, c / 8, h, w, k / 2, f16);
             return hipGetLastError();
