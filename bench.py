@@ -159,8 +159,8 @@ def init_control_plane(torch, rank, world, local_rank, force_gloo, timeout_s=300
 
 def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
     """The oracle (CPU restatement of the reference's path) timed on this host's cores: the thread count that does best
-    on this box (a sweep of one image each over {8, 16, 32, 64, all}: batch-1 convs on all 128 threads of the bench host
-    are oversubscribed), then the rest of the budget at that count; forward and NMS + formatting seconds apart."""
+    on this box (a sweep of one image each over {8, 16, 32, 64, all}, stopped at the first count 1.5x slower than the best:
+    batch-1 convs on all threads of the bench host are oversubscribed), then the rest of the budget at that count; forward and NMS + formatting seconds apart."""
     import torch
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     import parity_util as PU
@@ -187,13 +187,17 @@ def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
     counts = sorted(set(c for c in (8, 16, 32, 64) if c < cores) | {cores})
     sweep = {}
     for c in counts:
+        if len(sweep) >= 2 and time.perf_counter() - t_all + 2 * sweep[max(sweep)] > 0.7 * budget_s:
+            break                                # a slow host: the counts tried so far have to do
         torch.set_num_threads(c)
         one(small)
         t0 = time.perf_counter()
         one(imgs[0])
         sweep[c] = time.perf_counter() - t0
-        if time.perf_counter() - t_all > 0.7 * budget_s and len(sweep) >= 2:
-            break                                # a slow host: the counts tried so far have to do
+        if len(sweep) >= 2 and sweep[c] > 1.5 * min(sweep.values()):
+            # past the optimum it only gets worse, and fast: one image on all 256 hardware threads of a bench host took
+            # 117 s (round 6, the N = 2 line ran into its timeout); the sweep stops at the first count that is 1.5x off
+            break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     split = [0.0, 0.0]
@@ -491,6 +495,11 @@ def pmc_row_for_cfg(cfg_name):
 
 def main():
     args = parse_args()
+    if os.environ.get('MDHIP_BENCH_DUMP_AFTER'):
+        # a rank that is still running after this many seconds writes every thread's Python stack to stderr (and goes on):
+        # what a hung multi-rank launch was waiting for, without a debugger on the box
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['MDHIP_BENCH_DUMP_AFTER']), repeat=False, exit=False)
     gpus_given = args.gpus is not None
     if not gpus_given:                                        # `torchrun --nproc-per-node N bench.py` without --gpus: N ranks
         args.gpus = int(os.environ.get('WORLD_SIZE', '1'))
@@ -774,7 +783,9 @@ def main():
             # the rank was pinned to its GPU's share of the host; the baseline is the HOST's best, as in the N = 1 line
             try:
                 os.sched_setaffinity(0, range(os.cpu_count() or 1))
-                torch.set_num_threads(len(os.sched_getaffinity(0)))
+                # (the launcher exported OMP_NUM_THREADS=1; never more than 128 threads: batch-1 convs on every hardware
+                # thread of a 256-thread host are pathologically oversubscribed)
+                torch.set_num_threads(max(1, min(128, len(os.sched_getaffinity(0)))))
             except OSError:
                 pass
         cpu = cpu_baseline(weights, S, args.threshold, args.cpu_seconds, single_thread=not args.no_cpu_single_thread)
