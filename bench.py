@@ -531,14 +531,17 @@ def main():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)')
     # test hook: MDHIP_BENCH_ONE_GPU=1 runs every rank on device 0 with the gloo backend, so that the multi-rank code
     # path can be exercised on a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
-    one_gpu = os.environ.get('MDHIP_BENCH_ONE_GPU', '0') == '1'
-    if one_gpu:
+    # ('try': every rank on device 0 AND the RCCL attempt made -- RCCL refuses a duplicate device, which exercises the
+    # fall-back to gloo with a real RCCL failure on a real GPU box: profiles/r6_bench_2rank_rccl_refused.json)
+    hook = os.environ.get('MDHIP_BENCH_ONE_GPU', '0')
+    one_gpu = hook == '1'
+    if hook in ('1', 'try'):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     # one rank per GPU: CPUs of the GPU's NUMA node, disjoint from the other ranks' (the host thread formats 2.8 ms of
     # detections per step and keeps the queue fed; SURVEY.md 8(e) "scaling limiter")
     from megadetector_amd import placement
-    pinned_cpus = placement.pin_worker(local_rank, 1 if one_gpu else int(os.environ.get('LOCAL_WORLD_SIZE', world)), verbose=False,
+    pinned_cpus = placement.pin_worker(local_rank, 1 if hook in ('1', 'try') else int(os.environ.get('LOCAL_WORLD_SIZE', world)), verbose=False,
                                        force=args.pin_cpus)
     if world > 1 or args.pin_cpus:                             # stdout carries the one JSON line and nothing else
         print('rank {}: {} CPUs{}'.format(rank, len(pinned_cpus), ' ({}..{})'.format(pinned_cpus[0], pinned_cpus[-1])

@@ -34,6 +34,7 @@ cp $F/hbm_traffic.json ${P}_hbm_traffic.json
 [ -s $F/hbm_traffic_by_kernel.txt ] && cp $F/hbm_traffic_by_kernel.txt ${P}_hbm_traffic_by_kernel.txt
 [ -s $F/l2_hit_rate_by_kernel.txt ] && grep -v amdgpu $F/l2_hit_rate_by_kernel.txt > ${P}_l2_hit_rate_by_kernel.txt
 [ -s $F/bench_8rank_one_gpu_gloo.log ] && j $F/bench_8rank_one_gpu_gloo.log > ${P}_bench_8rank_one_gpu_gloo.json
+[ -s $F/bench_2rank_rccl_refused.log ] && j $F/bench_2rank_rccl_refused.log > ${P}_bench_2rank_rccl_refused.json
 [ -s $F/letterbox_bench.txt ] && grep -v amdgpu $F/letterbox_bench.txt > ${P}_letterbox_final_session.txt
 cp gpurun_out/pmc_final$R.txt ${P}_pmc_bench_kernels.txt
 cp gpurun_out/pmc_final$R.json ${P}_pmc_bench_kernels.json

@@ -79,6 +79,8 @@ left && MDHIP_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnod
 left && MDHIP_BENCH_ONE_GPU=1 timeout 300 python bench.py --gpus 2 --batch 8 --steps 30 --warmup 5 > $O/bench_selflaunch_2rank.log 2> $O/bench_selflaunch_2rank.err
 left && timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs --pin-cpus > $O/bench_pinned.log 2> $O/bench_pinned.err
 left && MDHIP_BENCH_ONE_GPU=1 timeout 400 python bench.py --gpus 8 --batch 2 --steps 20 --warmup 3 > $O/bench_8rank_one_gpu_gloo.log 2> $O/bench_8rank_one_gpu_gloo.err
+# a REAL RCCL failure: both ranks on device 0 with the RCCL attempt made (RCCL refuses the duplicate device) -> the line must come out over gloo, with the reason
+left && MDHIP_BENCH_ONE_GPU=try timeout 300 python bench.py --gpus 2 --batch 8 --steps 30 --warmup 5 > $O/bench_2rank_rccl_refused.log 2> $O/bench_2rank_rccl_refused.err
 left && timeout 200 python tools/letterbox_bench.py > $O/letterbox_bench.txt 2>&1
 left && timeout 400 python tools/e2e_feed_bench.py --n 4096 --workers 16,24 --out $O/e2e_feed.json > $O/e2e_feed.log 2>&1
 # the NUMA placement code on this box's topology (8 GPUs asked for: what the planner does with the GPUs it cannot see)
