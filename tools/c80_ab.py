@@ -38,8 +38,9 @@ def main():
     ops = [o['op'] for o in infos if o['kind'] == 0 and ctx.op_supports_cfg(o['op'], strips[0])]
     print('{} {}x{} batch {}: ops {}'.format(args.dtype, h, w, B, [infos[o]['name'] for o in ops]))
     ref = None
+    pre = [o - 1 for o in ops]                                   # the bottlenecks' 1x1 convs (absorbed when the block runs fused)
     for rnd in range(args.rounds):
-        for cfg in strips:
+        for cfg in [-1] + strips:                                # -1: whatever the tile table picks at this batch size
             for op in ops:
                 ctx.set_op_cfg(op, cfg)
             ctx.forward(B, h, w)
@@ -52,8 +53,10 @@ def main():
                 ms += ctx.forward_timed(B, h, w)
             ms /= args.reps
             skipped = sum(1 for o in ctx.op_infos() if o['kind'] == 0 and o['cfg'] < 0)
-            print('  {:<26} bottlenecks {}  = {:.4f} ms   forward (sum of op events) {:.3f} ms   1x1s absorbed {}   bits {}'.format(
-                ctx.conv_cfg_name(cfg), ' '.join('{:.4f}'.format(ms[o]) for o in ops), float(sum(ms[o] for o in ops)), float(ms.sum()), skipped,
+            name = ctx.conv_cfg_name(cfg) if cfg >= 0 else 'table: ' + ctx.conv_cfg_name(ctx.op_infos()[ops[0]]['cfg'])
+            print('  {:<34} bottlenecks (1x1 + 3x3) {}  = {:.4f} ms   forward (sum of op events) {:.3f} ms   1x1s absorbed {}   bits {}'.format(
+                name, ' '.join('{:.4f}'.format(ms[o] + (ms[q] if skipped == 0 else 0.0)) for o, q in zip(ops, pre)),
+                float(sum(ms[o] for o in ops) + (sum(ms[q] for q in pre) if skipped == 0 else 0.0)), float(ms.sum()), skipped,
                 'identical' if same else 'DIFFERENT'), flush=True)
     ctx.close()
 
