@@ -157,6 +157,24 @@ def init_control_plane(torch, rank, world, local_rank, force_gloo, timeout_s=300
     return dist, None, True, 'gloo', why
 
 
+def thread_sweep(cores, time_at, budget_s, clock=time.perf_counter):
+    """{thread count: seconds for one image} over {8, 16, 32, 64, cores} in rising order, `time_at(count)` doing the timing.
+    Stops (a) before a count when the counts tried so far already used most of the budget -- allowing for the next one to
+    take twice the last -- and (b) after the first count that is 1.5x slower than the best so far: past the optimum it only
+    gets worse, and fast (one image on all 256 hardware threads of a bench host took 117 s in round 6 and cost the N = 2
+    line its timeout).  At least two counts are tried when there are two."""
+    counts = sorted(set(c for c in (8, 16, 32, 64) if c < cores) | {cores})
+    t_all = clock()
+    sweep = {}
+    for c in counts:
+        if len(sweep) >= 2 and clock() - t_all + 2 * sweep[max(sweep)] > 0.7 * budget_s:
+            break
+        sweep[c] = time_at(c)
+        if len(sweep) >= 2 and sweep[c] > 1.5 * min(sweep.values()):
+            break
+    return sweep
+
+
 def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
     """The oracle (CPU restatement of the reference's path) timed on this host's cores: the thread count that does best
     on this box (a sweep of one image each over {8, 16, 32, 64, all}, stopped at the first count 1.5x slower than the best:
@@ -184,20 +202,15 @@ def cpu_baseline(weights, size, threshold, budget_s, single_thread=True):
     small = PU.random_images(1, 256, 256, seed=1)[0]
     one(small)                                   # warm-up (thread pools, allocator)
     t_all = time.perf_counter()
-    counts = sorted(set(c for c in (8, 16, 32, 64) if c < cores) | {cores})
-    sweep = {}
-    for c in counts:
-        if len(sweep) >= 2 and time.perf_counter() - t_all + 2 * sweep[max(sweep)] > 0.7 * budget_s:
-            break                                # a slow host: the counts tried so far have to do
+
+    def time_at(c):
         torch.set_num_threads(c)
         one(small)
         t0 = time.perf_counter()
         one(imgs[0])
-        sweep[c] = time.perf_counter() - t0
-        if len(sweep) >= 2 and sweep[c] > 1.5 * min(sweep.values()):
-            # past the optimum it only gets worse, and fast: one image on all 256 hardware threads of a bench host took
-            # 117 s (round 6, the N = 2 line ran into its timeout); the sweep stops at the first count that is 1.5x off
-            break
+        return time.perf_counter() - t0
+
+    sweep = thread_sweep(cores, time_at, budget_s)
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     split = [0.0, 0.0]

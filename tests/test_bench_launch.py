@@ -140,3 +140,32 @@ print(json.dumps([a == allowed, b, sorted(os.sched_getaffinity(0)), allowed]))
     untouched, pinned, mask, allowed = json.loads(r.stdout.strip().splitlines()[-1])
     assert untouched
     assert pinned == allowed[:max(1, len(allowed) // 2)] == mask
+
+
+def test_cpu_baseline_thread_sweep_stops_past_the_optimum_and_inside_the_budget():
+    """bench.thread_sweep: the thread-count sweep of the CPU baseline (north_star: the CPU path "timed on the same box's host
+    cores in the same run") must not be what an N > 1 line dies of.  Round 6: on a 256-thread host one image at 256 threads
+    took 117 s and the two-rank launch ran into its timeout.  With the timings of that host the sweep stops at 64 threads
+    (1.5x off the best); with a slow host it stops when the budget is nearly used; and it always tries two counts."""
+    import importlib
+    bench = importlib.import_module('bench')
+    host = {8: 1.02, 16: 0.87, 32: 0.99, 64: 1.58, 128: 3.3, 256: 117.0}
+    tried = []
+    now = [0.0]
+
+    def time_at(c):
+        tried.append(c)
+        now[0] += host[c]
+        return host[c]
+
+    sweep = bench.thread_sweep(256, time_at, 30.0, clock=lambda: now[0])
+    assert tried == [8, 16, 32, 64] and min(sweep, key=sweep.get) == 16, (tried, sweep)
+    # a host where every count takes 9 s: after two counts 18 s + 2 x 9 s > 0.7 x 30 s -> no third count
+    tried.clear()
+    now[0] = 0.0
+    slow = lambda c: (tried.append(c), now.__setitem__(0, now[0] + 9.0), 9.0)[2]
+    sweep = bench.thread_sweep(128, slow, 30.0, clock=lambda: now[0])
+    assert tried == [8, 16], tried
+    # a small host: its only count
+    tried.clear()
+    assert list(bench.thread_sweep(4, lambda c: (tried.append(c), 1.0)[1], 30.0, clock=lambda: 0.0)) == [4]

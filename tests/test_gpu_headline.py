@@ -433,6 +433,9 @@ def test_fused_bottleneck_is_bit_identical_to_the_two_launches(dtype):
             ctx.preprocess(imgs, _identity_geoms(imgs), hh, ww)
             ops = [o['op'] for o in ctx.op_infos() if o['kind'] == 0 and ctx.op_supports_cfg(o['op'], strip)]
             assert len(ops) == 4
+            # the stamped developer variants (dev:*, tools/convbench only) cannot be selected through the library
+            devs = [c for c in range(ctx.num_conv_cfgs()) if ctx.conv_cfg_name(c).startswith('dev:')]
+            assert devs and not any(ctx.op_supports_cfg(o['op'], c) for o in ctx.op_infos() if o['kind'] == 0 for c in devs)
             for op in ops:
                 ctx.set_op_cfg(op, strip)
             ctx.set_fuse(False)
