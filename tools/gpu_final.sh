@@ -9,7 +9,7 @@ R=${ROUND:-6}
 O=gpurun_out/final$R
 mkdir -p $O
 export TMPDIR=/tmp
-T0=$(date +%s); T_MAX=${T_MAX:-1300}
+T0=$(date +%s); T_MAX=${T_MAX:-2100}
 left() { [ $(( $(date +%s) - T0 )) -lt $T_MAX ]; }
 stamp() { echo "$1 at $(( $(date +%s) - T0 )) s" >> $O/timing.log; }
 (rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -6; nproc) > $O/env.txt 2>&1
