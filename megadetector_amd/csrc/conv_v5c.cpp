@@ -591,25 +591,40 @@ conv_c80d_kernel(const ConvArgs p) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) wp[t] = *(const __attribute__((address_space(3))) frag8_t*)(smem + lane_wp + t * 64);
         const f32x4 bpre4 = *(const __attribute__((address_space(3))) f32x4*)(smem + BPRE_OFF + (cf * 16 + kb * 4) * 4);
+        // Every fragment's reads first, then the MFMAs (k step outer: TF independent chains), then the SiLUs, then the writes.
+        // Fragment by fragment -- read, three dependent MFMAs, SiLU, ds_write, next fragment's read -- the LDS write of one
+        // fragment orders the reads of the next behind it (both are LDS: the compiler must assume they alias), and a task was
+        // five serial round trips: 500 cycles per fragment in the stamps.
+        frag8_t xf[TF][3];
+#pragma unroll
+        for (int f = 0; f < TF; ++f)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                // (t = 2: channels 64 .. 79, then the 32 bytes behind the pixel against zero weights)
+                xf[f][t] = *(const __attribute__((address_space(3))) frag8_t*)(smem + lane_x + st * RUNB + f * 16 * kPixB + t * 64);
+        f32x4 c[TF];
+#pragma unroll
+        for (int f = 0; f < TF; ++f) c[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int f = 0; f < TF; ++f) c[f] = MDHIP_MFMA(wp[t], xf[f][t], c[f]);
+        uint2 d[TF];
 #pragma unroll
         for (int f = 0; f < TF; ++f) {
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                // (t = 2: channels 64 .. 79, then the 32 bytes behind the pixel against zero weights)
-                const frag8_t xf = *(const __attribute__((address_space(3))) frag8_t*)(smem + lane_x + st * RUNB + f * 16 * kPixB + t * 64);
-                c = MDHIP_MFMA(wp[t], xf, c);
-            }
             const int px = f * 16 + m15;
             const bool ok = row_ok && px < BM + 2 && (unsigned)(x0 - 1 + px) < (unsigned)p.W;
             float v[4];
-            mdhip_bias4(c, bpre4, v);
+            mdhip_bias4(c[f], bpre4, v);
             mdhip_silu4(v);
-            uint2 d;
-            d.x = ok ? st_pack2(v[0], v[1]) : 0u;
-            d.y = ok ? st_pack2(v[2], v[3]) : 0u;
+            d[f].x = ok ? st_pack2(v[0], v[1]) : 0u;
+            d[f].y = ok ? st_pack2(v[2], v[3]) : 0u;
+        }
+#pragma unroll
+        for (int f = 0; f < TF; ++f) {
+            const int px = f * 16 + m15;
             if (px < BM + 2)
-                *(__attribute__((address_space(3))) uint2*)(smem + ts * RUNB + lane_t + f * 16 * kPixB) = d;
+                *(__attribute__((address_space(3))) uint2*)(smem + ts * RUNB + lane_t + f * 16 * kPixB) = d[f];
         }
     };
     auto ring_slot = [&](int i) __attribute__((always_inline)) -> int { return i >= NRING ? i - NRING : i; };
