@@ -490,7 +490,7 @@ constexpr int kD_BM = 64, kD_RW = 4, kD_RUNB = c80_run_bytes(kD_BM), kD_RING = k
 constexpr int kD_STAGE_OFF = kD_RING * kD_RUNB, kD_W1_OFF = kD_STAGE_OFF + kD_RW * kD_RUNB, kD_ZERO_OFF = kD_W1_OFF + kW1Bytes;
 constexpr int kD_WPRE_OFF = kD_ZERO_OFF + 256, kD_BPRE_OFF = kD_WPRE_OFF + 80 * 192, kD_LDS = kD_BPRE_OFF + 320;
 static_assert(kD_LDS <= 163840, "LDS of the four-row fused bottleneck");
-constexpr int kD_NB = 2, kD_RL = 5;                               // the shipped variant (see the template parameters)
+constexpr int kD_NB = 2, kD_RL = 4;                               // the shipped variant (see the template parameters)
 
 // PROF 1 (developer variant, tools/convbench with CONVBENCH_FUSED=1): s_memtime per phase of a tile into ConvArgs::dbg
 // NB: fragment buffers (steps st + 1 .. st + NB - 1 are in flight under step st); RL: first tap whose 64-channel weight
@@ -866,11 +866,11 @@ static const ConvCfg g_cfgs5c[] = {
 #undef X
     {kD_BM, 80, 640, (size_t)kD_LDS, 1, "v5:strip64x80/2x5/r4"},
     // (phase stamps; run only with ConvArgs::dbg set: tools/convbench)
-    {kD_BM, 80, 640, (size_t)kD_LDS, 1, "dev:strip64x80/2x5/r4/nb4rl3"},
+    {kD_BM, 80, 640, (size_t)kD_LDS, 1, "dev:strip64x80/2x5/r4/nb2rl4"},
     {kD_BM, 80, 640, (size_t)kD_LDS, 1, "dev:strip64x80/2x5/r4/nb2rl3"},
-    {kD_BM, 80, 640, (size_t)kD_LDS, 1, "dev:strip64x80/2x5/r4/nb3rl3"},
     {kD_BM, 80, 640, (size_t)kD_LDS, 1, "dev:strip64x80/2x5/r4/nb2rl5"},
-    {kD_BM, 80, 640, (size_t)kD_LDS, 1, "dev:strip64x80/2x5/r4/nb3rl5"},
+    {kD_BM, 80, 640, (size_t)kD_LDS, 1, "dev:strip64x80/2x5/r4/nb3rl3"},
+    {kD_BM, 80, 640, (size_t)kD_LDS, 1, "dev:strip64x80/2x5/r4/nb4rl3"},
 };
 
 
@@ -889,7 +889,7 @@ hipError_t conv5c_init() {
 
     MDHIP_CONV5C_CFGS(X)
 #undef X
-#define MDHIP_C80D_VARIANTS(X) X(0, 1, 4, 3) X(1, 1, 2, 3) X(2, 1, 3, 3) X(3, 1, 2, 5) X(4, 1, 3, 5)
+#define MDHIP_C80D_VARIANTS(X) X(0, 1, 2, 4) X(1, 1, 2, 3) X(2, 1, 2, 5) X(3, 1, 3, 3) X(4, 1, 4, 3)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_c80d_kernel<0, kD_NB, kD_RL>, hipFuncAttributeMaxDynamicSharedMemorySize, kD_LDS);
 #define X(id, prof, nb, rl) \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_c80d_kernel<prof, nb, rl>, hipFuncAttributeMaxDynamicSharedMemorySize, kD_LDS);
