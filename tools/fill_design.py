@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fills the «TOKEN» fields of DESIGN.md section 6 from the files of a final session under profiles/ (tools/collect_final.sh),
-so that the document's figures ARE the committed files'.  usage: python tools/fill_design.py [round] ; DESIGN.md.in -> DESIGN.md"""
+so that the document's figures ARE the committed files'.  usage: python tools/fill_design.py [round] ; docs/DESIGN.md.in -> DESIGN.md"""
 import csv
 import json
 import os
@@ -66,7 +66,7 @@ def main():
         'GT': m.group(1) if m else '?',
         'CT': os.environ.get('CPU_SUITE', '?'),
     }
-    src = open(os.path.join(REPO, 'DESIGN.md.in')).read()
+    src = open(os.path.join(REPO, 'docs', 'DESIGN.md.in')).read()
     missing = sorted(set(re.findall(r'«([A-Z0-9_]+)»', src)) - set(tok))
     if missing:
         sys.exit('no value for ' + ', '.join(missing))
