@@ -51,6 +51,11 @@ def main():
         if any(re.match(r'L(15|19|23) C3\.cv1\|cv2', nm) for nm, _ in r):
             print('skip   {} (reads an upsampled tensor in place)'.format([nm for nm, _ in r if 'cv1|cv2' in nm][0]))
             continue
+        if old[k]['name'].startswith('v5:strip'):
+            # the bottleneck 3x3s of an 80-channel block run as fused launches (1x1 + 3x3): an isolated op timing prices the
+            # plain strip kernel, not what runs (tools/c80_ab.py A/Bs those inside whole forwards)
+            print('skip   {} (fused bottleneck launch)'.format(r[0][0]))
+            continue
         if family(old[k]['name']) != family(e['name']):
             continue
         # (ops with and without residual share M, N, K: the row whose best figure is the re-tuned entry's own)
